@@ -1,0 +1,186 @@
+/*
+ * rm.h - C ABI of the MI355X ray-marching hot path.
+ *
+ * The reference renderer (joshua-jose/RayMarching) has no FFI: its seam is the
+ * Rust-internal call from main.rs into `Engine`.  Every entry point below names
+ * the reference interface it stands in for (file:line in the reference tree).
+ * All functions return 0 on success and a non-zero rm_status otherwise (the
+ * reference aborts instead); rm_last_error() describes the last failure on the
+ * calling thread.  Nothing here aborts the process.
+ *
+ * Threading: one engine is driven by one host thread at a time (the reference
+ * calls Engine from its main thread only, main.rs:141-145).
+ *
+ * Pixel format: 4 bytes per pixel, byte0 = blue, byte1 = green, byte2 = red,
+ * byte3 = 0, rows top to bottom - what the reference writes into its SDL
+ * ARGB8888 streaming texture (engine.rs:116-126, main.rs:56).
+ */
+#ifndef RM_H
+#define RM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rm_scene rm_scene;
+typedef struct rm_engine rm_engine;
+
+/* material.rs:2-9 */
+typedef struct rm_material {
+    float ambient;
+    float diffuse;
+    float specular;
+    float shininess;
+    float reflectivity;
+    float emissive;
+} rm_material;
+
+typedef enum rm_status {
+    RM_OK = 0,
+    RM_ERR_INVALID = 1,     /* bad argument */
+    RM_ERR_HIP = 2,         /* a HIP runtime call failed */
+    RM_ERR_UNSUPPORTED = 3, /* the reference itself aborts on this input */
+    RM_ERR_LIMIT = 4        /* a documented size limit was exceeded */
+} rm_status;
+
+/* Indices into the array filled by rm_engine_get_stats(). */
+enum {
+    RM_STAT_DEPTH_CAP_HITS = 0, /* reflection chains cut at RM_MAX_REFLECTION_DEPTH */
+    RM_STAT_STEP_CAP_HITS = 1,  /* marches cut by the optional iteration cap */
+    RM_STAT_LIGHTMAP_OOB = 2,   /* lightmap fetches the reference would abort on */
+    RM_STAT_TEXTURE_OOB = 3,
+    RM_STAT_COUNT = 8
+};
+
+#define RM_MAX_REFLECTION_DEPTH 16
+#define RM_MAX_OBJECTS 1024
+
+const char *rm_last_error(void);
+int rm_version(void);
+/* Number of HIP devices visible to the process. */
+int rm_device_count(int *count);
+
+/* ---- scene construction: main.rs:62-71,154-193 ------------------------- */
+
+/* `Vec<Box<dyn EngineObject>>` under construction (main.rs:154-193). */
+rm_scene *rm_scene_create(void);
+void rm_scene_destroy(rm_scene *scene);
+
+/* Texture::new (texture.rs:13-29) after the file decode: `rgb_topdown` is the
+ * decoded RGB8 image, rows top to bottom.  Returns the texture id (>= 0) or a
+ * negative rm_status. */
+int rm_texture_create_rgb8(rm_scene *scene, const uint8_t *rgb_topdown, int width, int height, float uscale,
+                           float vscale);
+
+/* Object constructors.  Objects keep insertion order; each returns the object
+ * index (>= 0) or a negative rm_status.
+ * Sphere{position,radius,material,colour,..}   objects.rs:158-165
+ * XPlane::new / YPlane::new / ZPlane::new       objects.rs:224-257
+ * Plane{normal,distance,..}                     objects.rs:167-175 */
+int rm_scene_add_sphere(rm_scene *scene, const float position[3], float radius, const rm_material *material,
+                        const float colour[3]);
+int rm_scene_add_xplane(rm_scene *scene, float x, float dir, const rm_material *material, const float colour[3]);
+int rm_scene_add_yplane(rm_scene *scene, float y, float dir, const rm_material *material, const float colour[3],
+                        int texture);
+int rm_scene_add_zplane(rm_scene *scene, float z, float dir, const rm_material *material, const float colour[3]);
+/* The reference cannot light or shade a generic Plane (its get_sample_pos and
+ * sample_uv_from_pos are unimplemented!(), objects.rs:39-42).  Here a Plane is
+ * rendered with the no-lightmap ambient of engine.rs:158 and takes no part in
+ * the radiosity clouds. */
+int rm_scene_add_plane(rm_scene *scene, const float normal[3], float distance, const rm_material *material,
+                       const float colour[3]);
+
+/* PointLight{position,intensity} and Engine.camera_position (main.rs:64-71). */
+int rm_scene_set_light(rm_scene *scene, const float position[3], float intensity);
+int rm_scene_set_camera(rm_scene *scene, const float position[3]);
+
+/* ---- engine ------------------------------------------------------------- */
+
+/* Engine{objects,camera_position,light} (engine.rs:329-333) bound to one HIP
+ * device.  width/height replace the compile-time WIDTH/HEIGHT (engine.rs:9-10)
+ * and map_size replaces MAP_SIZE (radiosity.rs:12; pass 8 for the reference's).
+ * The scene is copied: it may be destroyed afterwards. */
+rm_engine *rm_engine_create(const rm_scene *scene, int width, int height, int map_size, int device);
+void rm_engine_destroy(rm_engine *engine);
+
+/* Work is enqueued on `hip_stream` (a hipStream_t; NULL = the null stream). */
+int rm_engine_set_stream(rm_engine *engine, void *hip_stream);
+
+/* Engine::compute_lightmaps (engine.rs:246-326) with the bounce count of
+ * engine.rs:299 as a parameter (4 in the reference). */
+int rm_engine_compute_lightmaps(rm_engine *engine, int bounces);
+
+/* The same precompute in steps, for patch-sharded runs: receiver patches are
+ * numbered p = (cloud_object * map_size + x) * map_size + y.
+ *   begin        clouds (engine.rs:259-281) + direct lighting (radiosity.rs:52-101), all patches
+ *   form_factors visibility x geometry of radiosity.rs:126-152 for receivers [p0,p1)
+ *   bounce       radiosity.rs:159-196 for receivers [p0,p1): writes their slice of the
+ *                next emissive map and of the lightmap
+ *   commit       engine.rs:321-324: next emissive becomes current (after every rank's
+ *                slice has been gathered into the buffers below)
+ * rm_engine_radiosity_buffers exposes the device arrays a caller all-gathers:
+ * each is [n_patches][3] float; n_patches is returned too. */
+int rm_engine_radiosity_begin(rm_engine *engine);
+int rm_engine_radiosity_form_factors(rm_engine *engine, int p0, int p1);
+int rm_engine_radiosity_bounce(rm_engine *engine, int p0, int p1);
+int rm_engine_radiosity_commit(rm_engine *engine);
+int rm_engine_radiosity_buffers(rm_engine *engine, void **d_next_emissive, void **d_lightmaps, int *n_patches);
+
+/* EngineObject::get_lightmap / set_lightmap (objects.rs:34-35,216-217):
+ * `values` is [map_size][map_size][3] float, first index u (as sample_map[u][v]). */
+int rm_engine_get_lightmap(rm_engine *engine, int object, float *values);
+int rm_engine_set_lightmap(rm_engine *engine, int object, const float *values);
+
+/* The camera block of Engine::render (engine.rs:63-75): accumulated mouse
+ * position and scroll, and this frame's movement.  Stateful exactly as the
+ * reference: camera_position += rot(rel_move) on every call. */
+int rm_engine_input(rm_engine *engine, int32_t mouse_x, int32_t mouse_y, const float rel_move[3], int32_t scroll);
+int rm_engine_get_camera(rm_engine *engine, float position[3]);
+int rm_engine_set_camera(rm_engine *engine, const float position[3]);
+
+/* Engine::render (engine.rs:38-127): input block + all three passes, result
+ * copied to host memory.  `pitch_bytes` is the distance between rows (the
+ * reference ignores SDL's pitch and assumes width*4, engine.rs:88-89). */
+int rm_engine_render(rm_engine *engine, uint8_t *bgra, size_t pitch_bytes, int32_t mouse_x, int32_t mouse_y,
+                     const float rel_move[3], int32_t scroll);
+
+/* Passes 1-3 of Engine::render (engine.rs:77-126) for image rows
+ * [row_begin,row_end) at the pose of the last rm_engine_input, written to device
+ * memory; `d_bgra` points at the first byte of row `row_begin`.  Asynchronous on
+ * the engine's stream. */
+int rm_engine_render_rows_device(rm_engine *engine, void *d_bgra, size_t pitch_bytes, int row_begin, int row_end);
+
+/* FXAA (fxaa.txt:1-135, a commented-out block nothing in the reference calls),
+ * defined here out of place: every tap is read from `d_src`.  Both buffers hold
+ * whole frames of width*4-byte rows; rows [row_begin,row_end) of `d_dst` are
+ * written, reading rows row-1 .. row+4 of `d_src`. */
+int rm_engine_fxaa_device(rm_engine *engine, const void *d_src, void *d_dst, int row_begin, int row_end);
+
+/* Primary rays only (Ray::march from the camera, ray.rs:15-42): per pixel the
+ * hit object (-1 = none), the number of march iterations and the final ray
+ * position.  Host arrays of width*height (x3 for positions); any may be NULL. */
+int rm_engine_trace_primary(rm_engine *engine, int32_t *hit, int32_t *steps, float *position);
+
+/* Engine::shade_object (engine.rs:147-244) for `n` arbitrary hits: object index,
+ * position[3], view direction[3] in, linear colour[3] out (host arrays). */
+int rm_engine_probe_shade(rm_engine *engine, int n, const int32_t *object, const float *position,
+                          const float *direction, float *colour);
+
+/* Optional divergence cap on march iterations (0 = none; the loop of ray.rs:19
+ * ends by itself after at most 50/0.001 steps).  Cut marches are counted. */
+int rm_engine_set_march_cap(rm_engine *engine, int max_steps);
+
+/* Event counters accumulated since creation or the last reset (RM_STAT_*). */
+int rm_engine_get_stats(rm_engine *engine, uint64_t stats[RM_STAT_COUNT]);
+int rm_engine_reset_stats(rm_engine *engine);
+
+/* Block until everything enqueued on the engine's stream has finished. */
+int rm_engine_synchronize(rm_engine *engine);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RM_H */

@@ -1,0 +1,95 @@
+"""ctypes binding of the C ABI declared in include/rm.h (librm_hip.so).
+
+There is no fallback: if the HIP library is missing, loading raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librm_hip.so")
+
+RM_STAT_COUNT = 8
+STAT_NAMES = ("depth_cap_hits", "step_cap_hits", "lightmap_oob", "texture_oob")
+
+
+class Material(ctypes.Structure):
+    _fields_ = [(n, c_float) for n in ("ambient", "diffuse", "specular", "shininess", "reflectivity", "emissive")]
+
+
+_F3 = POINTER(c_float)
+
+# name -> (restype, argtypes); mirrors include/rm.h one to one
+SIGNATURES = {
+    "rm_last_error": (c_char_p, []),
+    "rm_version": (c_int, []),
+    "rm_device_count": (c_int, [POINTER(c_int)]),
+    "rm_scene_create": (c_void_p, []),
+    "rm_scene_destroy": (None, [c_void_p]),
+    "rm_texture_create_rgb8": (c_int, [c_void_p, POINTER(c_uint8), c_int, c_int, c_float, c_float]),
+    "rm_scene_add_sphere": (c_int, [c_void_p, _F3, c_float, POINTER(Material), _F3]),
+    "rm_scene_add_xplane": (c_int, [c_void_p, c_float, c_float, POINTER(Material), _F3]),
+    "rm_scene_add_yplane": (c_int, [c_void_p, c_float, c_float, POINTER(Material), _F3, c_int]),
+    "rm_scene_add_zplane": (c_int, [c_void_p, c_float, c_float, POINTER(Material), _F3]),
+    "rm_scene_add_plane": (c_int, [c_void_p, _F3, c_float, POINTER(Material), _F3]),
+    "rm_scene_set_light": (c_int, [c_void_p, _F3, c_float]),
+    "rm_scene_set_camera": (c_int, [c_void_p, _F3]),
+    "rm_engine_create": (c_void_p, [c_void_p, c_int, c_int, c_int, c_int]),
+    "rm_engine_destroy": (None, [c_void_p]),
+    "rm_engine_set_stream": (c_int, [c_void_p, c_void_p]),
+    "rm_engine_compute_lightmaps": (c_int, [c_void_p, c_int]),
+    "rm_engine_radiosity_begin": (c_int, [c_void_p]),
+    "rm_engine_radiosity_form_factors": (c_int, [c_void_p, c_int, c_int]),
+    "rm_engine_radiosity_bounce": (c_int, [c_void_p, c_int, c_int]),
+    "rm_engine_radiosity_commit": (c_int, [c_void_p]),
+    "rm_engine_radiosity_buffers": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int)]),
+    "rm_engine_get_lightmap": (c_int, [c_void_p, c_int, POINTER(c_float)]),
+    "rm_engine_set_lightmap": (c_int, [c_void_p, c_int, POINTER(c_float)]),
+    "rm_engine_input": (c_int, [c_void_p, c_int32, c_int32, _F3, c_int32]),
+    "rm_engine_get_camera": (c_int, [c_void_p, _F3]),
+    "rm_engine_set_camera": (c_int, [c_void_p, _F3]),
+    "rm_engine_render": (c_int, [c_void_p, POINTER(c_uint8), c_size_t, c_int32, c_int32, _F3, c_int32]),
+    "rm_engine_render_rows_device": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int]),
+    "rm_engine_fxaa_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    "rm_engine_trace_primary": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_float)]),
+    "rm_engine_probe_shade": (c_int, [c_void_p, c_int, POINTER(c_int32), POINTER(c_float), POINTER(c_float), POINTER(c_float)]),
+    "rm_engine_set_march_cap": (c_int, [c_void_p, c_int]),
+    "rm_engine_get_stats": (c_int, [c_void_p, POINTER(c_uint64)]),
+    "rm_engine_reset_stats": (c_int, [c_void_p]),
+    "rm_engine_synchronize": (c_int, [c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librm_hip.so and declare every entry point.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C raymarching_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+class RMError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rm_last_error()
+        raise RMError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+def f3(v):
+    return (c_float * 3)(float(v[0]), float(v[1]), float(v[2]))

@@ -1,0 +1,430 @@
+// Device-side arithmetic of the ray-marching hot path (gfx950).
+//
+// Compiled with -ffp-contract=off: every +,-,*,/ and sqrt below is one IEEE
+// binary32 operation in the order the reference evaluates it, so results match
+// a strict CPU evaluation bit for bit.  powf and atan2f are the only library
+// calls with a platform-defined last bit.
+//
+// Citations are file:line in the reference tree (src/...).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rm_types.hpp"
+
+namespace rm {
+
+#define RM_DEV __device__ __forceinline__
+
+struct V3 {
+    float x, y, z;
+};
+
+RM_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+RM_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RM_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RM_DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+RM_DEV V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+RM_DEV V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+RM_DEV V3 emul(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+
+// vector.rs:24: ordered lane sum of squares; the fourth lane is 0 whenever the
+// other three are not already NaN, so it never changes the sum.
+RM_DEV float mag_sqd(V3 a) { return (a.x * a.x + a.y * a.y) + a.z * a.z; }
+RM_DEV float mag(V3 a) { return sqrtf(mag_sqd(a)); }  // vector.rs:22
+// vector.rs:27-30: reciprocal then multiply
+RM_DEV V3 normalized(V3 a) {
+    float inv = 1.0f / mag(a);
+    return a * inv;
+}
+RM_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }  // vector.rs:32
+RM_DEV V3 reflect(V3 v, V3 n) { return v - n * (2.0f * dot(n, v)); }          // vector.rs:38
+
+// Rust f32::clamp keeps a NaN input; f32::min/max drop a NaN operand.
+RM_DEV float rs_clamp(float x, float lo, float hi) {
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return x;
+}
+RM_DEV float rs_max(float a, float b) { return fmaxf(a, b); }
+RM_DEV float rs_min(float a, float b) { return fminf(a, b); }
+
+RM_DEV float powi5(float x) {
+    float sq = x * x;
+    float q = sq * sq;
+    return x * q;
+}
+
+// Saturating float -> int casts with NaN -> 0, as Rust's `as`.
+RM_DEV int sat_i32(float f) {
+    if (!(f == f)) return 0;
+    if (f <= 0.0f) return 0;
+    if (f >= 1073741824.0f) return 1073741824;
+    return (int)f;
+}
+
+// objects.rs:334, 295, 275, 315, 261
+RM_DEV float sdf_eval(int type, float g0, float g1, float g2, float g3, V3 p) {
+    switch (type) {
+        case T_SPHERE: return mag(p - v3(g0, g1, g2)) - g3;
+        case T_XPLANE: return g1 * (p.x - g0);
+        case T_YPLANE: return g1 * (p.y - g0);
+        case T_ZPLANE: return g1 * (p.z - g0);
+        default: return ((p.x * g0 + p.y * g1) + p.z * g2) - g3;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Scene access for the march loops.  `Small` is indexed by unrolled constants
+// out of the kernel arguments (scalar registers); `Large` walks global arrays
+// with wave-uniform addresses (scalar loads).
+// ---------------------------------------------------------------------------
+
+struct SceneSmallAcc {
+    const SmallScene &s;
+    template <class F>
+    RM_DEV void for_each(F &&f) const {
+#pragma unroll
+        for (int i = 0; i < SMALL_SCENE; i++) {
+            if (i < s.n) f(i, s.type[i], s.geom[i].p[0], s.geom[i].p[1], s.geom[i].p[2], s.geom[i].p[3]);
+        }
+    }
+};
+
+struct SceneLargeAcc {
+    int n;
+    const int *__restrict__ type;
+    const Geom *__restrict__ geom;
+    template <class F>
+    RM_DEV void for_each(F &&f) const {
+        for (int i = 0; i < n; i++) {
+            Geom g = geom[i];
+            f(i, type[i], g.p[0], g.p[1], g.p[2], g.p[3]);
+        }
+    }
+};
+
+// ray.rs:15-42 (and ray.rs:58-85: every object type collides, objects.rs:220,343).
+// `ignore` < 0 means None.  Returns the hit object or -1; `pos` ends where the
+// reference leaves Ray::position.
+template <class SC>
+RM_DEV int march(const SC &sc, V3 &pos, V3 dir, int ignore, int cap, int &steps, bool &capped) {
+    float travelled = 0.0f;
+    steps = 0;
+    capped = false;
+    while (travelled < MAX_MARCH_DISTANCE) {
+        if (cap > 0 && steps >= cap) {
+            capped = true;
+            return -1;
+        }
+        steps++;
+        float d = __builtin_inff();
+        int idx = -1;
+        sc.for_each([&](int i, int type, float g0, float g1, float g2, float g3) {
+            float s = sdf_eval(type, g0, g1, g2, g3, pos);
+            if (i != ignore && s < d) {
+                d = s;
+                idx = i;
+            }
+        });
+        if (d < SMALL_DISTANCE) return idx;
+        travelled += d;
+        pos = pos + dir * d;
+    }
+    return -1;
+}
+
+// ray.rs:87-118
+template <class SC>
+RM_DEV float smooth_shadow_march(const SC &sc, V3 pos, V3 dir, int ignore, float light_dist, float k) {
+    float travelled = 0.0f;
+    float shade = 1.0f;
+    for (int it = 0; it < MAX_SHAD_IT; it++) {
+        float d = __builtin_inff();
+        sc.for_each([&](int i, int type, float g0, float g1, float g2, float g3) {
+            float s = sdf_eval(type, g0, g1, g2, g3, pos);
+            if (i != ignore && s < d) d = s;
+        });
+        float x = rs_clamp(k * d / travelled, 0.0f, 1.0f);
+        float ss = 3.0f * (x * x) - 2.0f * (x * (x * x));
+        shade = rs_min(shade, ss);
+        travelled += d;
+        pos = pos + dir * d;
+        if (d < SMALL_DISTANCE || travelled > light_dist) break;
+    }
+    return rs_clamp(shade, 0.0f, 1.0f);
+}
+
+// objects.rs:135-141 for a per-lane object
+RM_DEV V3 calculate_normal(int type, const Geom &g, V3 p) {
+    float g0 = g.p[0], g1 = g.p[1], g2 = g.p[2], g3 = g.p[3];
+    float gx = sdf_eval(type, g0, g1, g2, g3, v3(p.x + STEP_SIZE, p.y + 0.0f, p.z + 0.0f)) -
+               sdf_eval(type, g0, g1, g2, g3, v3(p.x - STEP_SIZE, p.y - 0.0f, p.z - 0.0f));
+    float gy = sdf_eval(type, g0, g1, g2, g3, v3(p.x + 0.0f, p.y + STEP_SIZE, p.z + 0.0f)) -
+               sdf_eval(type, g0, g1, g2, g3, v3(p.x - 0.0f, p.y - STEP_SIZE, p.z - 0.0f));
+    float gz = sdf_eval(type, g0, g1, g2, g3, v3(p.x + 0.0f, p.y + 0.0f, p.z + STEP_SIZE)) -
+               sdf_eval(type, g0, g1, g2, g3, v3(p.x - 0.0f, p.y - 0.0f, p.z - STEP_SIZE));
+    return normalized(v3(gx, gy, gz));
+}
+
+// objects.rs:285-290, 305-310, 325-330, 353-358
+RM_DEV void sample_uv_from_pos(int type, const Geom &g, V3 pos, float ms, float &u, float &v) {
+    const float half = ms / 2.0f;
+    switch (type) {
+        case T_SPHERE: {
+            V3 n = normalized(pos - v3(g.p[0], g.p[1], g.p[2]));
+            float uu = 0.5f + atan2f(n.x, -n.z) / 6.28318530717958647692f;
+            float vv = 0.5f + (n.y / 2.0f);
+            u = uu * ms;
+            v = vv * ms;
+            return;
+        }
+        case T_XPLANE:
+            u = pos.y + half - 0.5f;
+            v = pos.z + half - 0.5f;
+            return;
+        case T_YPLANE:
+            u = pos.x + half - 0.5f;
+            v = pos.z + half - 0.5f;
+            return;
+        default:  // T_ZPLANE
+            u = pos.x + half - 0.5f;
+            v = pos.y + half - 0.5f;
+            return;
+    }
+}
+
+// texture.rs:31-37
+RM_DEV V3 texture_sample(const TextureRec &t, float u, float v) {
+    float fx = fmodf(floorf(fabsf(u * t.uscale)), (float)t.w);
+    float fy = fmodf(floorf(fabsf(v * t.vscale)), (float)t.h);
+    int x = sat_i32(fx), y = sat_i32(fy);
+    x = min(x, t.w - 1);  // fmod keeps both below w/h; NaN maps to 0
+    y = min(y, t.h - 1);
+    const float *px = t.texels + 4 * (size_t)(x + y * t.w);
+    return v3(px[0], px[1], px[2]);
+}
+
+// objects.rs:260, 267-274, 294, 314, 336
+RM_DEV V3 object_colour(const SceneView &sv, const ShadeRec &sr, const Geom &g, V3 pos) {
+    if (sr.textured) {
+        float u, v;
+        sample_uv_from_pos(T_YPLANE, g, pos, (float)sv.map_size, u, v);
+        return texture_sample(sv.tex[sr.texture], u, v);
+    }
+    return v3(sr.cr, sr.cg, sr.cb);
+}
+
+RM_DEV V3 luxel(const SceneView &sv, const float *lm, int u, int v, bool &oob) {
+    const int M = sv.map_size;
+    if ((unsigned)u >= (unsigned)M || (unsigned)v >= (unsigned)M) {
+        oob = true;  // the reference aborts on this index
+        u = min(max(u, 0), M - 1);
+        v = min(max(v, 0), M - 1);
+    }
+    const float *p = lm + 3 * (u * M + v);
+    return v3(p[0], p[1], p[2]);
+}
+
+// objects.rs:45-133 with colour.rs:47-71 (the two sorts there leave the four
+// corners in the order they are passed in, because u0 < u1 and v0 < v1 always).
+RM_DEV V3 sample_lightmap(const SceneView &sv, const ShadeRec &sr, const Geom &g, V3 pos) {
+    const int M = sv.map_size;
+    const float *lm = sv.lightmaps + (size_t)sr.lm_slot * M * M * 3;
+    float u, v;
+    sample_uv_from_pos(sr.type, g, pos, (float)M, u, v);
+
+    int u0 = sat_i32(rs_max(floorf(u), 0.0f));
+    int v0 = sat_i32(rs_max(floorf(v), 0.0f));
+    int u1 = u0 + 1, v1 = v0 + 1;
+    u0 = (u0 >= M) ? u0 - 1 : u0;
+    v0 = (v0 >= M) ? v0 - 1 : v0;
+    u1 = (u1 >= M) ? u0 : u1;
+    v1 = (v1 >= M) ? v0 : v1;
+
+    bool oob = false;
+    V3 s00 = luxel(sv, lm, u0, v0, oob);
+    V3 s01 = luxel(sv, lm, u0, v1, oob);
+    V3 s10 = luxel(sv, lm, u1, v0, oob);
+    V3 s11 = luxel(sv, lm, u1, v1, oob);
+
+    bool resample = false;
+    if (mag_sqd(s00) == 0.0f) {
+        resample = true;
+        if (mag_sqd(s10) == 0.0f) {
+            v0 += 1;
+            v1 += 1;
+        } else if (mag_sqd(s11) == 0.0f) {
+            v0 -= 1;
+            v1 -= 1;
+        }
+        if (mag_sqd(s01) == 0.0f) {
+            u0 += 1;
+            u1 += 1;
+        } else if (mag_sqd(s11) == 0.0f) {
+            u0 -= 1;
+            u1 -= 1;
+        }
+    } else {
+        if (mag_sqd(s10) == 0.0f) {
+            resample = true;
+            u1 -= 1;
+        }
+        if (mag_sqd(s01) == 0.0f) {
+            resample = true;
+            v1 -= 1;
+        }
+    }
+    if (resample) {
+        s00 = luxel(sv, lm, u0, v0, oob);
+        s01 = luxel(sv, lm, u0, v1, oob);
+        s10 = luxel(sv, lm, u1, v0, oob);
+        s11 = luxel(sv, lm, u1, v1, oob);
+    }
+    if (oob) atomicAdd(&sv.stats[2], 1ULL);
+    if (u0 == u1) u1 += 1;
+    if (v0 == v1) v1 += 1;
+
+    // colour.rs:52-70 with (x1,y1)=(u0,v0): q11=s00, q12=s01, q21=s10, q22=s11
+    float x1 = (float)u0, x2 = (float)u1, y1 = (float)v0, y2 = (float)v1;
+    V3 acc = (((s00 * (x2 - u)) * (y2 - v)) + ((s10 * (u - x1)) * (y2 - v))) + ((s01 * (x2 - u)) * (v - y1));
+    acc = acc + ((s11 * (u - x1)) * (v - y1));
+    return acc / ((x2 - x1) * (y2 - y1));
+}
+
+// colour.rs:74-98
+RM_DEV void phong_ds(V3 n, V3 l, float dist, float intensity, const ShadeRec &m, V3 view, float &diffuse,
+                     float &specular) {
+    V3 r = reflect(l, n);
+    float li = intensity / (dist * dist);
+    diffuse = m.diffuse * li * rs_max(dot(l, n), 0.0f);
+    if (diffuse > 0.0f)
+        specular = m.specular * li * powf(rs_max(dot(r, view), 0.0f), m.shininess);
+    else
+        specular = 0.0f;
+}
+
+struct ShadeResult {
+    V3 final_colour;  // engine.rs:194
+    V3 object_colour;
+    V3 n;
+    float reflectivity;
+};
+
+// engine.rs:147-194: everything of shade_object before the reflection branch.
+template <class SC>
+RM_DEV ShadeResult shade_local(const SC &sc, const SceneView &sv, int idx, V3 pos, V3 dir) {
+    const ShadeRec sr = sv.shade[idx];
+    const Geom g = sv.geom[idx];
+    ShadeResult out;
+    V3 oc = object_colour(sv, sr, g, pos);
+    V3 n = calculate_normal(sr.type, g, pos);
+
+    V3 ambient;
+    if (sr.lm_slot < 0)
+        ambient = oc * sr.ambient;  // engine.rs:158
+    else
+        ambient = sample_lightmap(sv, sr, g, pos);  // engine.rs:159
+    if (mag_sqd(ambient) < sr.ambient * sr.ambient) ambient = normalized(ambient) * sr.ambient;  // engine.rs:163-165
+    ambient = emul(ambient, oc);                                                                  // engine.rs:168
+
+    V3 light = v3(sv.light[0], sv.light[1], sv.light[2]);
+    V3 to_light = light - pos;
+    float dist = mag(to_light);
+    to_light = to_light / dist;
+
+    float diffuse, specular;
+    phong_ds(n, to_light, dist, sv.intensity, sr, dir, diffuse, specular);
+    float shade = smooth_shadow_march(sc, pos, to_light, idx, dist, SHADOW_K);
+
+    out.final_colour = ambient + oc * (shade * (diffuse + specular));
+    out.object_colour = oc;
+    out.n = n;
+    out.reflectivity = sr.reflectivity;
+    return out;
+}
+
+// engine.rs:129-145 + 231-241 with the recursion turned into an explicit stack;
+// frames unwind innermost first, which keeps every rounding of the recursion.
+template <class SC>
+RM_DEV V3 cast_sight_ray(const SC &sc, const SceneView &sv, V3 pos, V3 dir) {
+    float stk[MAX_DEPTH][7];
+    int depth = 0;
+    V3 colour;
+    for (;;) {
+        int steps;
+        bool capped;
+        int idx = march(sc, pos, dir, -1, sv.march_cap, steps, capped);
+        if (capped) atomicAdd(&sv.stats[1], 1ULL);
+        if (idx < 0) {
+            colour = v3(sv.sky[0], sv.sky[1], sv.sky[2]);
+            break;
+        }
+        ShadeResult r = shade_local(sc, sv, idx, pos, dir);
+        if (r.reflectivity > 1e-3f) {
+            if (depth >= MAX_DEPTH) {
+                atomicAdd(&sv.stats[0], 1ULL);
+                colour = r.final_colour;
+                break;
+            }
+            float fresnel = powi5(rs_clamp(1.0f - dot(r.n, -dir), 0.0f, 1.0f));
+            V3 rv = reflect(dir, r.n);
+            float kk = rs_clamp(fresnel + r.reflectivity, 0.0f, 1.0f);
+            stk[depth][0] = r.final_colour.x;
+            stk[depth][1] = r.final_colour.y;
+            stk[depth][2] = r.final_colour.z;
+            stk[depth][3] = r.object_colour.x;
+            stk[depth][4] = r.object_colour.y;
+            stk[depth][5] = r.object_colour.z;
+            stk[depth][6] = kk;
+            depth++;
+            pos = pos + ((rv * 3.0f) * SMALL_DISTANCE);  // engine.rs:237
+            dir = rv;
+            continue;
+        }
+        colour = r.final_colour;
+        break;
+    }
+    while (depth > 0) {
+        depth--;
+        V3 f = v3(stk[depth][0], stk[depth][1], stk[depth][2]);
+        V3 oc = v3(stk[depth][3], stk[depth][4], stk[depth][5]);
+        colour = f + emul(colour, oc) * stk[depth][6];  // engine.rs:239-240
+    }
+    return colour;
+}
+
+// engine.rs:24-32
+RM_DEV V3 rot(V3 a, float sx, float cx, float sy, float cy) {
+    float x = a.x, y = a.y, z = a.z;
+    float ny = y * cy - z * sy, nz = y * sy + z * cy;
+    y = ny;
+    z = nz;
+    float nx = x * cx - z * sx;
+    nz = x * sx + z * cx;
+    return v3(nx, y, nz);
+}
+
+// engine.rs:79-84
+RM_DEV V3 pixel_direction(const Pose &p, int x, int y_inv) {
+    int y = p.H - y_inv;
+    float u = 2.0f * ((float)x - (0.5f * (float)p.W)) / (float)p.H;
+    float v = 2.0f * ((float)y - (0.5f * (float)p.H)) / (float)p.H;
+    return normalized(rot(v3(u, v, p.zdepth), p.sx, p.cx, p.sy, p.cy));
+}
+
+// colour.rs:33-44
+RM_DEV float aces(float x) { return (x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f); }
+
+// engine.rs:21-22
+RM_DEV unsigned to_pixel_range(float i) {
+    float v = rs_clamp(roundf(255.0f * i), 0.0f, 255.0f);
+    return (v == v) ? (unsigned)v : 0u;
+}
+
+// engine.rs:109-125 for one pixel: linear colour -> packed B,G,R,0 bytes
+RM_DEV unsigned pack_pixel(V3 linear, float exposure) {
+    V3 c = linear * exposure;
+    float r = sqrtf(aces(c.x)), g = sqrtf(aces(c.y)), b = sqrtf(aces(c.z));
+    return to_pixel_range(b) | (to_pixel_range(g) << 8) | (to_pixel_range(r) << 16);
+}
+
+}  // namespace rm

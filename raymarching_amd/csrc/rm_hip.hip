@@ -1,0 +1,1017 @@
+// HIP kernels and the C ABI (include/rm.h) of the ray-marching hot path, gfx950.
+//
+// Host side: scene flattening, device buffers, the camera block of
+// Engine::render (engine.rs:63-75) and launch geometry.  Device side: one
+// kernel for the whole per-pixel path (engine.rs:77-126), the radiosity
+// precompute (engine.rs:246-326, radiosity.rs) and FXAA (fxaa.txt).
+//
+// Citations are file:line in the reference tree (src/...).
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rm.h"
+#include "rm_device.hpp"
+#include "rm_types.hpp"
+
+using namespace rm;
+
+// ===========================================================================
+// Kernels
+// ===========================================================================
+
+// A wave is an 8x8 pixel tile, a workgroup 2x2 waves (16x16 pixels).
+constexpr int TILE = 8;
+constexpr int BLOCK_TILES_X = 2, BLOCK_TILES_Y = 2;
+constexpr int BLOCK_W = TILE * BLOCK_TILES_X, BLOCK_H = TILE * BLOCK_TILES_Y;
+constexpr int BLOCK_THREADS = 64 * BLOCK_TILES_X * BLOCK_TILES_Y;
+
+struct RenderArgs {
+    SceneView sv;
+    Pose pose;
+    int row_begin, row_end;
+    int blocks_x;
+    unsigned char *out;  // first byte of row `row_begin`
+    size_t pitch;
+};
+
+__device__ __forceinline__ void tile_pixel(int blocks_x, int row_begin, int &x, int &y_inv) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
+    x = bx * BLOCK_W + (wave % BLOCK_TILES_X) * TILE + (lane & 7);
+    y_inv = row_begin + by * BLOCK_H + (wave / BLOCK_TILES_X) * TILE + (lane >> 3);
+}
+
+// engine.rs:77-126 fused: direction, cast_sight_ray, tone map, pack.
+template <bool SMALL>
+__global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderArgs a, const SmallScene small) {
+    int x, y_inv;
+    tile_pixel(a.blocks_x, a.row_begin, x, y_inv);
+    if (x >= a.pose.W || y_inv >= a.row_end) return;
+    V3 dir = pixel_direction(a.pose, x, y_inv);
+    V3 cam = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
+    V3 colour;
+    if constexpr (SMALL) {
+        SceneSmallAcc sc{small};
+        colour = cast_sight_ray(sc, a.sv, cam, dir);
+    } else {
+        SceneLargeAcc sc{a.sv.n, a.sv.type, a.sv.geom};
+        colour = cast_sight_ray(sc, a.sv, cam, dir);
+    }
+    unsigned px = pack_pixel(colour, a.pose.exposure);
+    *reinterpret_cast<unsigned *>(a.out + (size_t)(y_inv - a.row_begin) * a.pitch + (size_t)x * 4) = px;
+}
+
+// Primary march only: hit object, iteration count, final position.
+template <bool SMALL>
+__global__ __launch_bounds__(BLOCK_THREADS) void trace_kernel(const RenderArgs a, const SmallScene small, int *hit,
+                                                              int *steps_out, float *pos_out) {
+    int x, y_inv;
+    tile_pixel(a.blocks_x, a.row_begin, x, y_inv);
+    if (x >= a.pose.W || y_inv >= a.row_end) return;
+    V3 dir = pixel_direction(a.pose, x, y_inv);
+    V3 pos = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
+    int steps, idx;
+    bool capped;
+    if constexpr (SMALL) {
+        SceneSmallAcc sc{small};
+        idx = march(sc, pos, dir, -1, a.sv.march_cap, steps, capped);
+    } else {
+        SceneLargeAcc sc{a.sv.n, a.sv.type, a.sv.geom};
+        idx = march(sc, pos, dir, -1, a.sv.march_cap, steps, capped);
+    }
+    size_t i = (size_t)y_inv * a.pose.W + x;
+    if (hit) hit[i] = idx;
+    if (steps_out) steps_out[i] = steps;
+    if (pos_out) {
+        pos_out[3 * i] = pos.x;
+        pos_out[3 * i + 1] = pos.y;
+        pos_out[3 * i + 2] = pos.z;
+    }
+}
+
+// Engine::shade_object at arbitrary points (engine.rs:147-244).
+template <bool SMALL>
+__global__ void probe_shade_kernel(const SceneView sv, const SmallScene small, int n, const int *obj, const float *pos,
+                                   const float *dir, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 p = v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+    V3 d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    int idx = obj[i];
+    auto body = [&](auto sc) {
+        ShadeResult r = shade_local(sc, sv, idx, p, d);
+        V3 c = r.final_colour;
+        if (r.reflectivity > 1e-3f) {
+            float fresnel = powi5(rs_clamp(1.0f - dot(r.n, -d), 0.0f, 1.0f));
+            V3 rv = reflect(d, r.n);
+            V3 rc = cast_sight_ray(sc, sv, p + ((rv * 3.0f) * SMALL_DISTANCE), rv);
+            c = c + emul(rc, r.object_colour) * rs_clamp(fresnel + r.reflectivity, 0.0f, 1.0f);
+        }
+        out[3 * i] = c.x;
+        out[3 * i + 1] = c.y;
+        out[3 * i + 2] = c.z;
+    };
+    if constexpr (SMALL)
+        body(SceneSmallAcc{small});
+    else
+        body(SceneLargeAcc{sv.n, sv.type, sv.geom});
+}
+
+// ---- radiosity -------------------------------------------------------------
+
+struct RadArgs {
+    SceneView sv;
+    int n_patches;          // n_lm * M * M
+    const int *patch_obj;   // [n_lm] engine index of each cloud object
+    const float *pos;       // [NP][3] point cloud (engine.rs:272)
+    float *col;             // [NP][3] colour cloud
+    float *nrm;             // [NP][3] normal cloud
+    float *emissive;        // [NP][3] current emissive maps
+    float *emissive_next;   // [NP][3]
+    float *lightmaps;       // [NP][3]
+    float *ft;              // [NP][NP] form factors, ft[j * NP + i]: source j -> receiver i; -1 = no contribution
+};
+
+// engine.rs:269-281: colour and normal of every sample point.
+__global__ void rad_cloud_kernel(const RadArgs a) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_patches) return;
+    const int mm = a.sv.map_size * a.sv.map_size;
+    int obj = a.patch_obj[p / mm];
+    V3 pos = v3(a.pos[3 * p], a.pos[3 * p + 1], a.pos[3 * p + 2]);
+    const ShadeRec sr = a.sv.shade[obj];
+    const Geom g = a.sv.geom[obj];
+    V3 c = object_colour(a.sv, sr, g, pos);
+    V3 n = calculate_normal(sr.type, g, pos);
+    a.col[3 * p] = c.x;
+    a.col[3 * p + 1] = c.y;
+    a.col[3 * p + 2] = c.z;
+    a.nrm[3 * p] = n.x;
+    a.nrm[3 * p + 1] = n.y;
+    a.nrm[3 * p + 2] = n.z;
+}
+
+// radiosity.rs:52-101
+template <bool SMALL>
+__global__ void rad_direct_kernel(const RadArgs a, const SmallScene small) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_patches) return;
+    const int mm = a.sv.map_size * a.sv.map_size;
+    int obj = a.patch_obj[p / mm];
+    const ShadeRec sr = a.sv.shade[obj];
+    const Geom g = a.sv.geom[obj];
+    V3 origin = v3(a.pos[3 * p], a.pos[3 * p + 1], a.pos[3 * p + 2]);
+    V3 colour = v3(a.col[3 * p], a.col[3 * p + 1], a.col[3 * p + 2]);
+    V3 light = v3(a.sv.light[0], a.sv.light[1], a.sv.light[2]);
+    V3 to_light = light - origin;
+    float dist = mag(to_light);
+    to_light = to_light / dist;
+    V3 rp = origin;
+    int steps;
+    bool capped;
+    if constexpr (SMALL)
+        march(SceneSmallAcc{small}, rp, to_light, obj, 0, steps, capped);
+    else
+        march(SceneLargeAcc{a.sv.n, a.sv.type, a.sv.geom}, rp, to_light, obj, 0, steps, capped);
+    V3 em = v3(0.0f, 0.0f, 0.0f), lm = v3(0.0f, 0.0f, 0.0f);
+    if (!(mag(rp - origin) < (dist + 3.0f * SMALL_DISTANCE))) {
+        V3 n = calculate_normal(sr.type, g, origin);
+        float diffuse = rs_max(dot(n, to_light), 0.0f) * a.sv.intensity / (dist * dist);
+        em = colour * (diffuse + sr.emissive);
+        lm = colour * sr.emissive;
+    }
+    a.emissive[3 * p] = em.x;
+    a.emissive[3 * p + 1] = em.y;
+    a.emissive[3 * p + 2] = em.z;
+    a.lightmaps[3 * p] = lm.x;
+    a.lightmaps[3 * p + 1] = lm.y;
+    a.lightmaps[3 * p + 2] = lm.z;
+}
+
+// radiosity.rs:119-152 for one (receiver i, source j) pair: everything of the
+// inner loop that does not depend on the bounce.  x = receiver, y = source.
+template <bool SMALL>
+__global__ void rad_form_kernel(const RadArgs a, const SmallScene small, int p0, int p1) {
+    int i = p0 + blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y;
+    if (i >= p1) return;
+    const int mm = a.sv.map_size * a.sv.map_size;
+    float f = -1.0f;
+    if (i / mm != j / mm) {  // radiosity.rs:112: no self illumination
+        int recv_obj = a.patch_obj[i / mm];
+        V3 sample_pos = v3(a.pos[3 * i], a.pos[3 * i + 1], a.pos[3 * i + 2]);
+        V3 sample_n = v3(a.nrm[3 * i], a.nrm[3 * i + 1], a.nrm[3 * i + 2]);
+        V3 src = v3(a.pos[3 * j], a.pos[3 * j + 1], a.pos[3 * j + 2]);
+        V3 src_n = v3(a.nrm[3 * j], a.nrm[3 * j + 1], a.nrm[3 * j + 2]);
+        V3 to_light = src - sample_pos;
+        float dist = mag(to_light);
+        to_light = to_light / dist;
+        V3 back = -to_light;
+        V3 rp = src + back * (3.0f * SMALL_DISTANCE);  // radiosity.rs:131
+        int steps, hit;
+        bool capped;
+        if constexpr (SMALL)
+            hit = march(SceneSmallAcc{small}, rp, back, -1, 0, steps, capped);
+        else
+            hit = march(SceneLargeAcc{a.sv.n, a.sv.type, a.sv.geom}, rp, back, -1, 0, steps, capped);
+        bool blocked = (hit >= 0) && (hit != recv_obj) && (mag_sqd(rp - sample_pos) > 0.1f * 0.1f);
+        if (!blocked) {
+            float att = dot(sample_n, to_light) * -dot(src_n, to_light);
+            float diffuse = rs_max(att, 0.0f) / (dist * dist);
+            f = rs_min(diffuse, 2.0f);
+        }
+    }
+    a.ft[(size_t)j * a.n_patches + i] = f;
+}
+
+// radiosity.rs:107-156 + 184-192 for one receiver: the ordered sum over sources.
+__global__ void rad_bounce_kernel(const RadArgs a, int p0, int p1) {
+    int i = p0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p1) return;
+    const int NP = a.n_patches;
+    V3 incident = v3(0.0f, 0.0f, 0.0f);
+    for (int j = 0; j < NP; j++) {
+        float f = a.ft[(size_t)j * NP + i];
+        if (f != -1.0f) {
+            V3 e = v3(a.emissive[3 * j], a.emissive[3 * j + 1], a.emissive[3 * j + 2]);
+            incident = incident + e * f;
+        }
+    }
+    incident = incident / 3.14159265358979323846f;
+    V3 col = v3(a.col[3 * i], a.col[3 * i + 1], a.col[3 * i + 2]);
+    a.lightmaps[3 * i] = a.lightmaps[3 * i] + incident.x;
+    a.lightmaps[3 * i + 1] = a.lightmaps[3 * i + 1] + incident.y;
+    a.lightmaps[3 * i + 2] = a.lightmaps[3 * i + 2] + incident.z;
+    V3 ne = emul(incident, col);
+    a.emissive_next[3 * i] = ne.x;
+    a.emissive_next[3 * i + 1] = ne.y;
+    a.emissive_next[3 * i + 2] = ne.z;
+}
+
+// ---- FXAA (fxaa.txt:1-135, out of place) -------------------------------------
+
+__device__ __forceinline__ void fx_load(const unsigned char *src, size_t i, float c[3]) {
+    unsigned px = *reinterpret_cast<const unsigned *>(src + i * 4);
+    c[0] = (float)(px & 255u) / 255.0f;
+    c[1] = (float)((px >> 8) & 255u) / 255.0f;
+    c[2] = (float)((px >> 16) & 255u) / 255.0f;
+}
+__device__ __forceinline__ float fx_luma(const float c[3]) { return (0.299f * c[0] + 0.587f * c[1]) + 0.114f * c[2]; }
+// `as usize` of a rounded offset: negative and NaN become 0
+__device__ __forceinline__ int fx_off(float o) { return sat_i32(roundf(o)); }
+__device__ __forceinline__ unsigned fx_u8(float f) {
+    if (!(f == f) || f <= 0.0f) return 0u;
+    if (f >= 255.0f) return 255u;
+    return (unsigned)f;
+}
+
+__global__ __launch_bounds__(256) void fxaa_kernel(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst,
+                                                   int W, int H, int row_begin, int row_end) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y_inv = row_begin + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y_inv >= row_end) return;
+    size_t i = (size_t)y_inv * W + x;
+    unsigned centre = *reinterpret_cast<const unsigned *>(src + i * 4);
+    if (x < 4 || x >= W - 4 || y_inv < 4 || y_inv >= H - 4) {  // fxaa.txt:7-8 leaves the border untouched
+        *reinterpret_cast<unsigned *>(dst + i * 4) = centre;
+        return;
+    }
+    float nw[3], ne[3], sw[3], se[3], m[3];
+    fx_load(src, i - W - 1, nw);
+    fx_load(src, i - W + 1, ne);
+    fx_load(src, i + W - 1, sw);
+    fx_load(src, i + W + 1, se);
+    fx_load(src, i, m);
+    float lNW = fx_luma(nw), lNE = fx_luma(ne), lSW = fx_luma(sw), lSE = fx_luma(se), lM = fx_luma(m);
+    float lmin = rs_min(lM, rs_min(rs_min(lNW, lNE), rs_min(lSW, lSE)));
+    float lmax = rs_max(lM, rs_max(rs_max(lNW, lNE), rs_max(lSW, lSE)));
+    float d0 = -((lNW + lNE) - (lSW + lSE));
+    float d1 = (lNW + lSW) - (lNE + lSE);
+    float reduce = rs_max((((lNW + lNE) + lSW) + lSE) * (0.25f * (1.0f / 8.0f)), 1.0f / 128.0f);
+    float rcp = 1.0f / (rs_min(fabsf(d0), fabsf(d1)) + reduce);
+    d0 = rs_min(8.0f, rs_max(-8.0f, d0 * rcp));
+    d1 = rs_min(8.0f, rs_max(-8.0f, d1 * rcp));
+    const float kA0 = 1.0f / 3.0f - 0.5f, kA1 = 2.0f / 2.0f - 0.5f, kB0 = 0.0f / 3.0f - 0.5f, kB1 = 3.0f / 3.0f - 0.5f;
+    size_t iA0 = (size_t)(y_inv + fx_off(d1 * kA0)) * W + (size_t)(x + fx_off(d0 * kA0));
+    size_t iA1 = (size_t)(y_inv + fx_off(d1 * kA1)) * W + (size_t)(x + fx_off(d0 * kA1));
+    size_t iB0 = (size_t)(y_inv + fx_off(d1 * kB0)) * W + (size_t)(x + fx_off(d0 * kB0));
+    size_t iB1 = (size_t)(y_inv + fx_off(d1 * kB1)) * W + (size_t)(x + fx_off(d0 * kB1));
+    float a0[3], a1[3], b0[3], b1[3], A[3], B[3];
+    fx_load(src, iA0, a0);
+    fx_load(src, iA1, a1);
+    fx_load(src, iB0, b0);
+    fx_load(src, iB1, b1);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        A[c] = 0.5f * (a0[c] + a1[c]);
+        B[c] = A[c] * 0.5f + 0.25f * (b0[c] + b1[c]);
+    }
+    float lB = fx_luma(B);
+    const bool useA = (lB < lmin) || (lB > lmax);
+    unsigned o0 = fx_u8(255.0f * (useA ? A[0] : B[0]));
+    unsigned o1 = fx_u8(255.0f * (useA ? A[1] : B[1]));
+    unsigned o2 = fx_u8(255.0f * (useA ? A[2] : B[2]));
+    *reinterpret_cast<unsigned *>(dst + i * 4) = o0 | (o1 << 8) | (o2 << 16) | (centre & 0xFF000000u);
+}
+
+// ===========================================================================
+// Host runtime
+// ===========================================================================
+
+static thread_local std::string g_error;
+
+static int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(RM_ERR_HIP, std::string(#expr) + " failed: " + hipGetErrorString(e__));         \
+    } while (0)
+
+struct HostObject {
+    int type;
+    float p[4];
+    rm_material mat;
+    float colour[3];
+    int texture;
+};
+
+struct HostTexture {
+    std::vector<float> texels;  // [h][w][4]
+    int w, h;
+    float uscale, vscale;
+};
+
+struct rm_scene {
+    std::vector<HostObject> objects;
+    std::vector<HostTexture> textures;
+    float light[3] = {0.0f, 0.0f, 0.0f};
+    float intensity = 1.0f;
+    float camera[3] = {0.0f, 0.0f, 0.0f};
+};
+
+struct rm_engine {
+    int device = 0;
+    int W = 0, H = 0, M = 8;
+    hipStream_t stream = nullptr;
+    rm_scene scene;  // private copy
+    float camera[3];
+    Pose pose;
+    int march_cap = 0;
+
+    // device-resident scene
+    int n = 0, n_lm = 0, n_patches = 0;
+    bool small = false;
+    SmallScene small_scene;
+    std::vector<int> lm_slot;    // per object, -1 = none
+    std::vector<int> patch_obj;  // per lightmap slot: engine index
+    int *d_type = nullptr;
+    Geom *d_geom = nullptr;
+    ShadeRec *d_shade = nullptr;
+    TextureRec *d_tex = nullptr;
+    std::vector<float *> d_texels;
+    float *d_lightmaps = nullptr;  // [n_patches][3]
+    unsigned long long *d_stats = nullptr;
+    unsigned char *d_frame = nullptr;  // W*H*4, for rm_engine_render
+
+    // radiosity work buffers
+    int *d_patch_obj = nullptr;
+    float *d_pos = nullptr, *d_col = nullptr, *d_nrm = nullptr;
+    float *d_emissive = nullptr, *d_emissive_next = nullptr;
+    float *d_ft = nullptr;
+    bool rad_begun = false;
+
+    SceneView view() const {
+        SceneView sv;
+        sv.n = n;
+        sv.type = d_type;
+        sv.geom = d_geom;
+        sv.shade = d_shade;
+        sv.tex = d_tex;
+        sv.lightmaps = d_lightmaps;
+        sv.map_size = M;
+        for (int i = 0; i < 3; i++) sv.light[i] = scene.light[i];
+        sv.intensity = scene.intensity;
+        // engine.rs:15 SKY_COLOUR = rgb![135, 206, 235]
+        const float sky8[3] = {135.0f, 206.0f, 235.0f};
+        for (int i = 0; i < 3; i++) sv.sky[i] = (sky8[i] / 255.0f) * (sky8[i] / 255.0f);
+        sv.march_cap = march_cap;
+        sv.stats = d_stats;
+        return sv;
+    }
+    RadArgs rad_args() const {
+        RadArgs a;
+        a.sv = view();
+        a.n_patches = n_patches;
+        a.patch_obj = d_patch_obj;
+        a.pos = d_pos;
+        a.col = d_col;
+        a.nrm = d_nrm;
+        a.emissive = d_emissive;
+        a.emissive_next = d_emissive_next;
+        a.lightmaps = d_lightmaps;
+        a.ft = d_ft;
+        return a;
+    }
+};
+
+// engine.rs:24-32 on the host (camera movement)
+static void host_rot(const float v[3], float sx, float cx, float sy, float cy, float out[3]) {
+    float x = v[0], y = v[1], z = v[2];
+    float ny = y * cy - z * sy, nz = y * sy + z * cy;
+    y = ny;
+    z = nz;
+    float nx = x * cx - z * sx;
+    nz = x * sx + z * cx;
+    out[0] = nx;
+    out[1] = y;
+    out[2] = nz;
+}
+
+// objects.rs:278-284, 298-304, 318-324, 345-352 (sin/cos stay on the host)
+static bool host_sample_pos(const HostObject &o, int M, int u, int v, float out[3]) {
+    const float MS = (float)M;
+    const float a = ((float)u) - (MS / 2.0f) + 0.5f;
+    const float b = ((float)v) - (MS / 2.0f) + 0.5f;
+    switch (o.type) {
+        case T_SPHERE: {
+            const float PI = 3.14159265358979323846f;
+            float theta = ((((float)u / MS) * 2.0f) - 1.0f) * PI;
+            float phi = (((float)v / MS) - 0.5f) * PI;
+            float nx = sinf(theta), ny = sinf(phi), nz = -cosf(theta);
+            out[0] = o.p[0] + nx * o.p[3];
+            out[1] = o.p[1] + ny * o.p[3];
+            out[2] = o.p[2] + nz * o.p[3];
+            return true;
+        }
+        case T_XPLANE: out[0] = o.p[0]; out[1] = a; out[2] = b; return true;
+        case T_YPLANE: out[0] = a; out[1] = o.p[0]; out[2] = b; return true;
+        case T_ZPLANE: out[0] = a; out[1] = b; out[2] = o.p[0]; return true;
+        default: return false;
+    }
+}
+
+template <class T>
+static hipError_t dev_alloc(T **p, size_t count) {
+    return hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T));
+}
+
+static int engine_upload(rm_engine *e) {
+    const rm_scene &s = e->scene;
+    e->n = (int)s.objects.size();
+    e->small = e->n <= SMALL_SCENE;
+    std::vector<int> type(e->n);
+    std::vector<Geom> geom(e->n);
+    std::vector<ShadeRec> shade(e->n);
+    e->lm_slot.assign(e->n, -1);
+    e->patch_obj.clear();
+    memset(&e->small_scene, 0, sizeof(SmallScene));
+    e->small_scene.n = e->small ? e->n : 0;
+    for (int i = 0; i < e->n; i++) {
+        const HostObject &o = s.objects[i];
+        type[i] = o.type;
+        memcpy(geom[i].p, o.p, sizeof(float) * 4);
+        ShadeRec r;
+        memset(&r, 0, sizeof(r));
+        r.ambient = o.mat.ambient;
+        r.diffuse = o.mat.diffuse;
+        r.specular = o.mat.specular;
+        r.shininess = o.mat.shininess;
+        r.reflectivity = o.mat.reflectivity;
+        r.emissive = o.mat.emissive;
+        r.cr = o.colour[0];
+        r.cg = o.colour[1];
+        r.cb = o.colour[2];
+        r.type = o.type;
+        r.texture = o.texture;
+        r.textured = (o.type == T_YPLANE && !(o.p[0] > 0.0f)) ? 1 : 0;  // objects.rs:268
+        if (o.type != T_PLANE) {
+            r.lm_slot = (int)e->patch_obj.size();
+            e->lm_slot[i] = r.lm_slot;
+            e->patch_obj.push_back(i);
+        } else {
+            r.lm_slot = -1;
+        }
+        shade[i] = r;
+        if (e->small) {
+            e->small_scene.type[i] = o.type;
+            memcpy(e->small_scene.geom[i].p, o.p, sizeof(float) * 4);
+        }
+    }
+    e->n_lm = (int)e->patch_obj.size();
+    e->n_patches = e->n_lm * e->M * e->M;
+
+    HIP_TRY(dev_alloc(&e->d_type, e->n));
+    HIP_TRY(dev_alloc(&e->d_geom, e->n));
+    HIP_TRY(dev_alloc(&e->d_shade, e->n));
+    HIP_TRY(hipMemcpy(e->d_type, type.data(), sizeof(int) * e->n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_geom, geom.data(), sizeof(Geom) * e->n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_shade, shade.data(), sizeof(ShadeRec) * e->n, hipMemcpyHostToDevice));
+
+    std::vector<TextureRec> tex(s.textures.size());
+    e->d_texels.assign(s.textures.size(), nullptr);
+    for (size_t t = 0; t < s.textures.size(); t++) {
+        const HostTexture &ht = s.textures[t];
+        HIP_TRY(dev_alloc(&e->d_texels[t], ht.texels.size()));
+        HIP_TRY(hipMemcpy(e->d_texels[t], ht.texels.data(), sizeof(float) * ht.texels.size(), hipMemcpyHostToDevice));
+        tex[t] = TextureRec{e->d_texels[t], ht.w, ht.h, ht.uscale, ht.vscale};
+    }
+    HIP_TRY(dev_alloc(&e->d_tex, tex.size()));
+    if (!tex.empty()) HIP_TRY(hipMemcpy(e->d_tex, tex.data(), sizeof(TextureRec) * tex.size(), hipMemcpyHostToDevice));
+
+    HIP_TRY(dev_alloc(&e->d_lightmaps, (size_t)e->n_patches * 3));
+    HIP_TRY(hipMemset(e->d_lightmaps, 0, std::max<size_t>((size_t)e->n_patches * 3, 1) * sizeof(float)));
+    HIP_TRY(dev_alloc(&e->d_stats, RM_STAT_COUNT));
+    HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * RM_STAT_COUNT));
+    HIP_TRY(dev_alloc(&e->d_patch_obj, e->n_lm));
+    if (e->n_lm)
+        HIP_TRY(hipMemcpy(e->d_patch_obj, e->patch_obj.data(), sizeof(int) * e->n_lm, hipMemcpyHostToDevice));
+    return RM_OK;
+}
+
+static void engine_free(rm_engine *e) {
+    (void)hipSetDevice(e->device);
+    (void)hipFree(e->d_type);
+    (void)hipFree(e->d_geom);
+    (void)hipFree(e->d_shade);
+    (void)hipFree(e->d_tex);
+    for (float *p : e->d_texels) (void)hipFree(p);
+    (void)hipFree(e->d_lightmaps);
+    (void)hipFree(e->d_stats);
+    (void)hipFree(e->d_frame);
+    (void)hipFree(e->d_patch_obj);
+    (void)hipFree(e->d_pos);
+    (void)hipFree(e->d_col);
+    (void)hipFree(e->d_nrm);
+    (void)hipFree(e->d_emissive);
+    (void)hipFree(e->d_emissive_next);
+    (void)hipFree(e->d_ft);
+}
+
+static RenderArgs make_render_args(rm_engine *e, void *d_out, size_t pitch, int row_begin, int row_end, dim3 &grid) {
+    RenderArgs a;
+    a.sv = e->view();
+    a.pose = e->pose;
+    a.row_begin = row_begin;
+    a.row_end = row_end;
+    a.blocks_x = (e->W + BLOCK_W - 1) / BLOCK_W;
+    a.out = static_cast<unsigned char *>(d_out);
+    a.pitch = pitch;
+    int blocks_y = (row_end - row_begin + BLOCK_H - 1) / BLOCK_H;
+    grid = dim3((unsigned)(a.blocks_x * blocks_y), 1, 1);
+    return a;
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+
+extern "C" {
+
+const char *rm_last_error(void) { return g_error.c_str(); }
+int rm_version(void) { return 1; }
+
+int rm_device_count(int *count) {
+    if (!count) return fail(RM_ERR_INVALID, "count is NULL");
+    HIP_TRY(hipGetDeviceCount(count));
+    return RM_OK;
+}
+
+rm_scene *rm_scene_create(void) { return new rm_scene(); }
+void rm_scene_destroy(rm_scene *scene) { delete scene; }
+
+int rm_texture_create_rgb8(rm_scene *scene, const uint8_t *rgb, int width, int height, float uscale, float vscale) {
+    if (!scene || !rgb || width <= 0 || height <= 0) return -fail(RM_ERR_INVALID, "bad texture arguments");
+    HostTexture t;
+    t.w = width;
+    t.h = height;
+    t.uscale = uscale;
+    t.vscale = vscale;
+    t.texels.resize((size_t)width * height * 4);
+    for (size_t i = 0; i < (size_t)width * height; i++) {
+        for (int c = 0; c < 3; c++) {
+            float f = (float)rgb[3 * i + c];
+            t.texels[4 * i + c] = (f / 255.0f) * (f / 255.0f);  // colour.rs:7-15 via texture.rs:18-21
+        }
+        t.texels[4 * i + 3] = 0.0f;
+    }
+    scene->textures.push_back(std::move(t));
+    return (int)scene->textures.size() - 1;
+}
+
+static int add_object(rm_scene *scene, int type, const float p[4], const rm_material *m, const float colour[3],
+                      int texture) {
+    if (!scene || !m || !colour) return -fail(RM_ERR_INVALID, "NULL argument");
+    if (scene->objects.size() >= RM_MAX_OBJECTS) return -fail(RM_ERR_LIMIT, "too many objects");
+    HostObject o;
+    o.type = type;
+    memcpy(o.p, p, sizeof(float) * 4);
+    o.mat = *m;
+    memcpy(o.colour, colour, sizeof(float) * 3);
+    o.texture = texture;
+    scene->objects.push_back(o);
+    return (int)scene->objects.size() - 1;
+}
+
+int rm_scene_add_sphere(rm_scene *scene, const float position[3], float radius, const rm_material *material,
+                        const float colour[3]) {
+    if (!position) return -fail(RM_ERR_INVALID, "NULL position");
+    float p[4] = {position[0], position[1], position[2], radius};
+    return add_object(scene, T_SPHERE, p, material, colour, -1);
+}
+int rm_scene_add_xplane(rm_scene *scene, float x, float dir, const rm_material *material, const float colour[3]) {
+    float p[4] = {x, dir, 0.0f, 0.0f};
+    return add_object(scene, T_XPLANE, p, material, colour, -1);
+}
+int rm_scene_add_yplane(rm_scene *scene, float y, float dir, const rm_material *material, const float colour[3],
+                        int texture) {
+    if (!scene || texture < 0 || texture >= (int)scene->textures.size())
+        return -fail(RM_ERR_INVALID, "YPlane::new takes a texture (objects.rs:236)");
+    float p[4] = {y, dir, 0.0f, 0.0f};
+    return add_object(scene, T_YPLANE, p, material, colour, texture);
+}
+int rm_scene_add_zplane(rm_scene *scene, float z, float dir, const rm_material *material, const float colour[3]) {
+    float p[4] = {z, dir, 0.0f, 0.0f};
+    return add_object(scene, T_ZPLANE, p, material, colour, -1);
+}
+int rm_scene_add_plane(rm_scene *scene, const float normal[3], float distance, const rm_material *material,
+                       const float colour[3]) {
+    if (!normal) return -fail(RM_ERR_INVALID, "NULL normal");
+    float p[4] = {normal[0], normal[1], normal[2], distance};
+    return add_object(scene, T_PLANE, p, material, colour, -1);
+}
+int rm_scene_set_light(rm_scene *scene, const float position[3], float intensity) {
+    if (!scene || !position) return fail(RM_ERR_INVALID, "NULL argument");
+    memcpy(scene->light, position, sizeof(float) * 3);
+    scene->intensity = intensity;
+    return RM_OK;
+}
+int rm_scene_set_camera(rm_scene *scene, const float position[3]) {
+    if (!scene || !position) return fail(RM_ERR_INVALID, "NULL argument");
+    memcpy(scene->camera, position, sizeof(float) * 3);
+    return RM_OK;
+}
+
+rm_engine *rm_engine_create(const rm_scene *scene, int width, int height, int map_size, int device) {
+    if (!scene || width <= 0 || height <= 0 || map_size <= 0 || map_size > 256) {
+        fail(RM_ERR_INVALID, "bad engine arguments");
+        return nullptr;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        fail(RM_ERR_HIP, "no HIP device is visible: the ray-marching kernels need an MI355X");
+        return nullptr;
+    }
+    if (device < 0 || device >= count) {
+        fail(RM_ERR_INVALID, "device index out of range");
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        fail(RM_ERR_HIP, "hipSetDevice failed");
+        return nullptr;
+    }
+    rm_engine *e = new rm_engine();
+    e->device = device;
+    e->W = width;
+    e->H = height;
+    e->M = map_size;
+    e->scene = *scene;
+    memcpy(e->camera, scene->camera, sizeof(float) * 3);
+    if (engine_upload(e) != RM_OK) {
+        engine_free(e);
+        delete e;
+        return nullptr;
+    }
+    const float zero[3] = {0.0f, 0.0f, 0.0f};
+    rm_engine_input(e, 0, 0, zero, 0);
+    return e;
+}
+
+void rm_engine_destroy(rm_engine *engine) {
+    if (!engine) return;
+    engine_free(engine);
+    delete engine;
+}
+
+int rm_engine_set_stream(rm_engine *e, void *hip_stream) {
+    if (!e) return fail(RM_ERR_INVALID, "NULL engine");
+    e->stream = static_cast<hipStream_t>(hip_stream);
+    return RM_OK;
+}
+
+int rm_engine_input(rm_engine *e, int32_t mouse_x, int32_t mouse_y, const float rel_move[3], int32_t scroll) {
+    if (!e || !rel_move) return fail(RM_ERR_INVALID, "NULL argument");
+    Pose &p = e->pose;
+    p.exposure = 1.0f;                               // engine.rs:63
+    float theta_x = (float)(-mouse_x) / 600.0f;      // engine.rs:65
+    float theta_y = (float)mouse_y / 600.0f;         // engine.rs:66
+    p.sx = sinf(theta_x);
+    p.cx = cosf(theta_x);
+    p.sy = sinf(theta_y);
+    p.cy = cosf(theta_y);
+    float moved[3];
+    host_rot(rel_move, p.sx, p.cx, p.sy, p.cy, moved);  // engine.rs:72
+    for (int i = 0; i < 3; i++) e->camera[i] = e->camera[i] + moved[i];
+    float fov_deg = 90.0f - ((float)scroll * 5.0f);  // engine.rs:74
+    const float PI = 3.14159265358979323846f;
+    float rad = (fov_deg * 0.5f) * (PI / 180.0f);
+    p.zdepth = 1.0f / tanf(rad);  // engine.rs:75
+    for (int i = 0; i < 3; i++) p.cam[i] = e->camera[i];
+    p.W = e->W;
+    p.H = e->H;
+    return RM_OK;
+}
+
+int rm_engine_get_camera(rm_engine *e, float position[3]) {
+    if (!e || !position) return fail(RM_ERR_INVALID, "NULL argument");
+    memcpy(position, e->camera, sizeof(float) * 3);
+    return RM_OK;
+}
+int rm_engine_set_camera(rm_engine *e, const float position[3]) {
+    if (!e || !position) return fail(RM_ERR_INVALID, "NULL argument");
+    memcpy(e->camera, position, sizeof(float) * 3);
+    memcpy(e->pose.cam, position, sizeof(float) * 3);
+    return RM_OK;
+}
+
+int rm_engine_render_rows_device(rm_engine *e, void *d_bgra, size_t pitch_bytes, int row_begin, int row_end) {
+    if (!e || !d_bgra) return fail(RM_ERR_INVALID, "NULL argument");
+    if (row_begin < 0 || row_end > e->H || row_begin > row_end) return fail(RM_ERR_INVALID, "row range outside the frame");
+    if (pitch_bytes < (size_t)e->W * 4 || (pitch_bytes & 3)) return fail(RM_ERR_INVALID, "pitch must be >= width*4 and a multiple of 4");
+    if (row_begin == row_end) return RM_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    dim3 grid;
+    RenderArgs a = make_render_args(e, d_bgra, pitch_bytes, row_begin, row_end, grid);
+    if (e->small)
+        hipLaunchKernelGGL(render_kernel<true>, grid, dim3(BLOCK_THREADS), 0, e->stream, a, e->small_scene);
+    else
+        hipLaunchKernelGGL(render_kernel<false>, grid, dim3(BLOCK_THREADS), 0, e->stream, a, e->small_scene);
+    HIP_TRY(hipGetLastError());
+    return RM_OK;
+}
+
+int rm_engine_render(rm_engine *e, uint8_t *bgra, size_t pitch_bytes, int32_t mouse_x, int32_t mouse_y,
+                     const float rel_move[3], int32_t scroll) {
+    if (!e || !bgra) return fail(RM_ERR_INVALID, "NULL argument");
+    if (pitch_bytes < (size_t)e->W * 4) return fail(RM_ERR_INVALID, "pitch must be >= width*4");
+    int rc = rm_engine_input(e, mouse_x, mouse_y, rel_move, scroll);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->d_frame) HIP_TRY(dev_alloc(&e->d_frame, (size_t)e->W * e->H * 4));
+    rc = rm_engine_render_rows_device(e, e->d_frame, (size_t)e->W * 4, 0, e->H);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(bgra, pitch_bytes, e->d_frame, (size_t)e->W * 4, (size_t)e->W * 4, e->H,
+                             hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RM_OK;
+}
+
+int rm_engine_fxaa_device(rm_engine *e, const void *d_src, void *d_dst, int row_begin, int row_end) {
+    if (!e || !d_src || !d_dst) return fail(RM_ERR_INVALID, "NULL argument");
+    if (d_src == d_dst) return fail(RM_ERR_INVALID, "FXAA runs out of place: source and destination must differ");
+    if (row_begin < 0 || row_end > e->H || row_begin > row_end) return fail(RM_ERR_INVALID, "row range outside the frame");
+    if (row_begin == row_end) return RM_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    dim3 grid((e->W + 63) / 64, (row_end - row_begin + 3) / 4);
+    hipLaunchKernelGGL(fxaa_kernel, grid, dim3(256), 0, e->stream, static_cast<const unsigned char *>(d_src),
+                       static_cast<unsigned char *>(d_dst), e->W, e->H, row_begin, row_end);
+    HIP_TRY(hipGetLastError());
+    return RM_OK;
+}
+
+int rm_engine_trace_primary(rm_engine *e, int32_t *hit, int32_t *steps, float *position) {
+    if (!e) return fail(RM_ERR_INVALID, "NULL engine");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t npx = (size_t)e->W * e->H;
+    int *d_hit = nullptr, *d_steps = nullptr;
+    float *d_pos = nullptr;
+    HIP_TRY(dev_alloc(&d_hit, npx));
+    HIP_TRY(dev_alloc(&d_steps, npx));
+    HIP_TRY(dev_alloc(&d_pos, npx * 3));
+    dim3 grid;
+    RenderArgs a = make_render_args(e, d_hit, (size_t)e->W * 4, 0, e->H, grid);
+    if (e->small)
+        hipLaunchKernelGGL(trace_kernel<true>, grid, dim3(BLOCK_THREADS), 0, e->stream, a, e->small_scene, d_hit,
+                           d_steps, d_pos);
+    else
+        hipLaunchKernelGGL(trace_kernel<false>, grid, dim3(BLOCK_THREADS), 0, e->stream, a, e->small_scene, d_hit,
+                           d_steps, d_pos);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (err == hipSuccess && hit) err = hipMemcpy(hit, d_hit, npx * sizeof(int), hipMemcpyDeviceToHost);
+    if (err == hipSuccess && steps) err = hipMemcpy(steps, d_steps, npx * sizeof(int), hipMemcpyDeviceToHost);
+    if (err == hipSuccess && position) err = hipMemcpy(position, d_pos, npx * 3 * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_hit);
+    (void)hipFree(d_steps);
+    (void)hipFree(d_pos);
+    if (err != hipSuccess) return fail(RM_ERR_HIP, std::string("trace_primary: ") + hipGetErrorString(err));
+    return RM_OK;
+}
+
+int rm_engine_probe_shade(rm_engine *e, int n, const int32_t *object, const float *position, const float *direction,
+                          float *colour) {
+    if (!e || !object || !position || !direction || !colour || n < 0) return fail(RM_ERR_INVALID, "bad argument");
+    if (n == 0) return RM_OK;
+    for (int i = 0; i < n; i++)
+        if (object[i] < 0 || object[i] >= e->n) return fail(RM_ERR_INVALID, "object index out of range");
+    HIP_TRY(hipSetDevice(e->device));
+    int *d_obj = nullptr;
+    float *d_pos = nullptr, *d_dir = nullptr, *d_out = nullptr;
+    HIP_TRY(dev_alloc(&d_obj, n));
+    HIP_TRY(dev_alloc(&d_pos, (size_t)n * 3));
+    HIP_TRY(dev_alloc(&d_dir, (size_t)n * 3));
+    HIP_TRY(dev_alloc(&d_out, (size_t)n * 3));
+    hipError_t err = hipMemcpy(d_obj, object, sizeof(int) * n, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d_pos, position, sizeof(float) * 3 * n, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d_dir, direction, sizeof(float) * 3 * n, hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        dim3 grid((n + 63) / 64);
+        if (e->small)
+            hipLaunchKernelGGL(probe_shade_kernel<true>, grid, dim3(64), 0, e->stream, e->view(), e->small_scene, n,
+                               d_obj, d_pos, d_dir, d_out);
+        else
+            hipLaunchKernelGGL(probe_shade_kernel<false>, grid, dim3(64), 0, e->stream, e->view(), e->small_scene, n,
+                               d_obj, d_pos, d_dir, d_out);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (err == hipSuccess) err = hipMemcpy(colour, d_out, sizeof(float) * 3 * n, hipMemcpyDeviceToHost);
+    (void)hipFree(d_obj);
+    (void)hipFree(d_pos);
+    (void)hipFree(d_dir);
+    (void)hipFree(d_out);
+    if (err != hipSuccess) return fail(RM_ERR_HIP, std::string("probe_shade: ") + hipGetErrorString(err));
+    return RM_OK;
+}
+
+// ---- radiosity -------------------------------------------------------------
+
+int rm_engine_radiosity_begin(rm_engine *e) {
+    if (!e) return fail(RM_ERR_INVALID, "NULL engine");
+    HIP_TRY(hipSetDevice(e->device));
+    const int NP = e->n_patches, M = e->M;
+    if (!e->d_pos) {
+        HIP_TRY(dev_alloc(&e->d_pos, (size_t)NP * 3));
+        HIP_TRY(dev_alloc(&e->d_col, (size_t)NP * 3));
+        HIP_TRY(dev_alloc(&e->d_nrm, (size_t)NP * 3));
+        HIP_TRY(dev_alloc(&e->d_emissive, (size_t)NP * 3));
+        HIP_TRY(dev_alloc(&e->d_emissive_next, (size_t)NP * 3));
+    }
+    e->rad_begun = true;
+    if (NP == 0) return RM_OK;
+    // engine.rs:269-273: the world position of every sample point
+    std::vector<float> pos((size_t)NP * 3);
+    for (int ci = 0; ci < e->n_lm; ci++) {
+        const HostObject &o = e->scene.objects[e->patch_obj[ci]];
+        for (int x = 0; x < M; x++)
+            for (int y = 0; y < M; y++)
+                if (!host_sample_pos(o, M, x, y, &pos[((size_t)(ci * M + x) * M + y) * 3]))
+                    return fail(RM_ERR_UNSUPPORTED, "object type has no lightmap parameterisation");
+    }
+    HIP_TRY(hipMemcpyAsync(e->d_pos, pos.data(), sizeof(float) * pos.size(), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // `pos` is pageable host memory
+    HIP_TRY(hipMemsetAsync(e->d_emissive_next, 0, sizeof(float) * 3 * NP, e->stream));
+    RadArgs a = e->rad_args();
+    dim3 grid((NP + 63) / 64);
+    hipLaunchKernelGGL(rad_cloud_kernel, grid, dim3(64), 0, e->stream, a);
+    if (e->small)
+        hipLaunchKernelGGL(rad_direct_kernel<true>, grid, dim3(64), 0, e->stream, a, e->small_scene);
+    else
+        hipLaunchKernelGGL(rad_direct_kernel<false>, grid, dim3(64), 0, e->stream, a, e->small_scene);
+    HIP_TRY(hipGetLastError());
+    return RM_OK;
+}
+
+static int check_patch_range(rm_engine *e, int p0, int p1) {
+    if (!e) return fail(RM_ERR_INVALID, "NULL engine");
+    if (!e->rad_begun) return fail(RM_ERR_INVALID, "call rm_engine_radiosity_begin first");
+    if (p0 < 0 || p1 > e->n_patches || p0 > p1) return fail(RM_ERR_INVALID, "patch range outside [0, n_patches]");
+    return RM_OK;
+}
+
+int rm_engine_radiosity_form_factors(rm_engine *e, int p0, int p1) {
+    int rc = check_patch_range(e, p0, p1);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    const int NP = e->n_patches;
+    if (!e->d_ft) HIP_TRY(dev_alloc(&e->d_ft, (size_t)NP * NP));
+    if (p0 == p1) return RM_OK;
+    if (NP > 65535) return fail(RM_ERR_LIMIT, "more than 65535 patches");
+    RadArgs a = e->rad_args();
+    dim3 grid((p1 - p0 + 63) / 64, NP);
+    if (e->small)
+        hipLaunchKernelGGL(rad_form_kernel<true>, grid, dim3(64), 0, e->stream, a, e->small_scene, p0, p1);
+    else
+        hipLaunchKernelGGL(rad_form_kernel<false>, grid, dim3(64), 0, e->stream, a, e->small_scene, p0, p1);
+    HIP_TRY(hipGetLastError());
+    return RM_OK;
+}
+
+int rm_engine_radiosity_bounce(rm_engine *e, int p0, int p1) {
+    int rc = check_patch_range(e, p0, p1);
+    if (rc) return rc;
+    if (!e->d_ft) return fail(RM_ERR_INVALID, "call rm_engine_radiosity_form_factors first");
+    if (p0 == p1) return RM_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    RadArgs a = e->rad_args();
+    dim3 grid((p1 - p0 + 63) / 64);
+    hipLaunchKernelGGL(rad_bounce_kernel, grid, dim3(64), 0, e->stream, a, p0, p1);
+    HIP_TRY(hipGetLastError());
+    return RM_OK;
+}
+
+int rm_engine_radiosity_commit(rm_engine *e) {
+    if (!e || !e->rad_begun) return fail(RM_ERR_INVALID, "radiosity not begun");
+    HIP_TRY(hipSetDevice(e->device));
+    if (e->n_patches)
+        HIP_TRY(hipMemcpyAsync(e->d_emissive, e->d_emissive_next, sizeof(float) * 3 * e->n_patches,
+                               hipMemcpyDeviceToDevice, e->stream));
+    return RM_OK;
+}
+
+int rm_engine_radiosity_buffers(rm_engine *e, void **d_next_emissive, void **d_lightmaps, int *n_patches) {
+    if (!e || !e->rad_begun) return fail(RM_ERR_INVALID, "radiosity not begun");
+    if (d_next_emissive) *d_next_emissive = e->d_emissive_next;
+    if (d_lightmaps) *d_lightmaps = e->d_lightmaps;
+    if (n_patches) *n_patches = e->n_patches;
+    return RM_OK;
+}
+
+int rm_engine_compute_lightmaps(rm_engine *e, int bounces) {
+    if (!e || bounces < 0) return fail(RM_ERR_INVALID, "bad argument");
+    int rc = rm_engine_radiosity_begin(e);
+    if (rc) return rc;
+    if (bounces > 0) {
+        rc = rm_engine_radiosity_form_factors(e, 0, e->n_patches);
+        if (rc) return rc;
+    }
+    for (int b = 0; b < bounces; b++) {
+        rc = rm_engine_radiosity_bounce(e, 0, e->n_patches);
+        if (rc) return rc;
+        rc = rm_engine_radiosity_commit(e);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RM_OK;
+}
+
+int rm_engine_get_lightmap(rm_engine *e, int object, float *values) {
+    if (!e || !values || object < 0 || object >= e->n) return fail(RM_ERR_INVALID, "bad argument");
+    int slot = e->lm_slot[object];
+    if (slot < 0) return fail(RM_ERR_UNSUPPORTED, "object has no lightmap");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t count = (size_t)e->M * e->M * 3;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(values, e->d_lightmaps + slot * count, count * sizeof(float), hipMemcpyDeviceToHost));
+    return RM_OK;
+}
+
+int rm_engine_set_lightmap(rm_engine *e, int object, const float *values) {
+    if (!e || !values || object < 0 || object >= e->n) return fail(RM_ERR_INVALID, "bad argument");
+    int slot = e->lm_slot[object];
+    if (slot < 0) return fail(RM_ERR_UNSUPPORTED, "object has no lightmap");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t count = (size_t)e->M * e->M * 3;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->d_lightmaps + slot * count, values, count * sizeof(float), hipMemcpyHostToDevice));
+    return RM_OK;
+}
+
+int rm_engine_set_march_cap(rm_engine *e, int max_steps) {
+    if (!e || max_steps < 0) return fail(RM_ERR_INVALID, "bad argument");
+    e->march_cap = max_steps;
+    return RM_OK;
+}
+
+int rm_engine_get_stats(rm_engine *e, uint64_t stats[RM_STAT_COUNT]) {
+    if (!e || !stats) return fail(RM_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(stats, e->d_stats, sizeof(uint64_t) * RM_STAT_COUNT, hipMemcpyDeviceToHost));
+    return RM_OK;
+}
+int rm_engine_reset_stats(rm_engine *e) {
+    if (!e) return fail(RM_ERR_INVALID, "NULL engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemsetAsync(e->d_stats, 0, sizeof(uint64_t) * RM_STAT_COUNT, e->stream));
+    return RM_OK;
+}
+
+int rm_engine_synchronize(rm_engine *e) {
+    if (!e) return fail(RM_ERR_INVALID, "NULL engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RM_OK;
+}
+
+}  // extern "C"
