@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Headline benchmark: primary Mrays/s of the default scene at 3840x2160 on N MI355X.
+
+One "step" is one frame: every primary ray of the 4K image through march, shading
+(texture, lightmap, Phong, soft shadow, reflections), tone map and pack, written
+as B,G,R,0 bytes into HBM.  With N > 1 the frame is split into N row bands, one
+per rank, and the bands are all-gathered over RCCL so that every rank ends up with
+the whole frame (strong scaling: the work per frame is fixed).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak (counts an FMA as 2 flops)
+PEAK_FP32_NO_FMA_TFLOPS = 78.65  # same issue rate without fused multiply-add
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--fxaa", action="store_true", help="add the FXAA pass to every frame")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the CPU baseline leg")
+    ap.add_argument("--no-overlap", action="store_true", help="wait for each frame's all-gather before the next render")
+    return ap.parse_args()
+
+
+def load_counters(width, height):
+    path = os.path.join(ROOT, "tests", "golden", "counters.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(f"frame_pose0_{width}x{height}")
+    except OSError:
+        return None
+
+
+def cpu_baseline(scene, lightmaps, width, height, budget_s):
+    """Times the CPU oracle (test infrastructure) on whole frames of the same workload
+    until about `budget_s` seconds of CPU work have been spent (at least 3 frames)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    e = oracle.OracleEngine(scene)
+    for i in range(e.n_objects):
+        e.set_lightmap(i, lightmaps[i])
+    e.render(width, height, row_step=16, threads=threads)  # warm-up: thread pool, caches
+    times = []
+    frame = None
+    t_start = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        frame = e.render(width, height, threads=threads)
+        times.append(time.perf_counter() - t0)
+        if len(times) >= 200:
+            break
+    e.close()
+    times.sort()
+    median = times[len(times) // 2]
+    rays = width * height
+    return {
+        "value": rays / median / 1e6,
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{len(times)} whole {width}x{height} frames ({rays} primary rays each), median {median * 1e3:.1f} ms/frame, "
+        f"{sum(times):.1f} s of wall time, OpenMP over rows as the reference's rayon",
+    }, frame
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the ray-marching kernels need an MI355X", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from raymarching_amd import Engine, default_scene
+    from raymarching_amd.dist import band_rows
+    from raymarching_amd.flops import frame_flops
+
+    W, H = args.width, args.height
+    scene = default_scene()
+    eng = Engine(scene, W, H, device=local_rank)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+    eng.compute_lightmaps(4)  # main.rs:73: once, before the frame loop (not timed)
+    eng.input(0, 0, (0.0, 0.0, 0.0), 0)  # first-frame pose (main.rs:78-80,122)
+
+    band_h = (H + world - 1) // world
+    r0, r1 = band_rows(H, rank, world)
+    # double-buffered so that the gather of frame f overlaps the render of frame f+1
+    bands = [torch.zeros((band_h, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    frames = [torch.zeros((world * band_h, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    fx_src = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") if args.fxaa else None
+
+    kernel_events = []
+
+    def render_band(buf, timed):
+        if timed:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev0.record(stream)
+        if args.fxaa:
+            # band plus the rows FXAA reads around it (one above, four below)
+            h0, h1 = max(r0 - 1, 0), min(r1 + 4, H)
+            eng.render_rows_device(fx_src[h0].data_ptr(), h0, h1)
+            if timed:
+                ev1.record(stream)
+            # the band buffer stands in for rows r0.. of a frame-shaped destination
+            eng.fxaa_device(fx_src.data_ptr(), buf.data_ptr() - r0 * W * 4, r0, r1)
+        else:
+            eng.render_rows_device(buf.data_ptr(), r0, r1)
+            if timed:
+                ev1.record(stream)
+        if timed:
+            kernel_events.append((ev0, ev1))
+
+    def run(steps, timed):
+        pending = None
+        for s in range(steps):
+            b = s & 1
+            render_band(bands[b], timed)
+            if world > 1:
+                if pending is not None:
+                    pending.wait()
+                pending = dist.all_gather_into_tensor(frames[b].view(-1), bands[b].view(-1), async_op=True)
+                if args.no_overlap:
+                    pending.wait()
+                    pending = None
+        if pending is not None:
+            pending.wait()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup, False)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
+    stats = eng.stats()
+
+    result = None
+    if rank == 0:
+        rays = W * H
+        ms_per_step = elapsed / args.steps * 1e3
+        counters = load_counters(W, H)
+        roofline = None
+        if counters is not None:
+            band_share = (r1 - r0) / H  # flops are counted for the whole frame; a band is its share by rows
+            flops = frame_flops(counters)
+            achieved = flops * band_share / (kernel_ms * 1e-3) / 1e12
+            roofline = {
+                "bound": "valu",
+                "achieved": achieved,
+                "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_TFLOPS,
+                "frac_of_no_fma_peak": achieved / PEAK_FP32_NO_FMA_TFLOPS,
+                "traffic": None,
+                "kernel": "render_kernel",
+                "kernel_ms": kernel_ms,
+                "algorithmic_flops_per_launch": int(flops * band_share),
+                "note": "FP32 vector ALU bound (no MFMA, HBM traffic is 4 B per ray); strict IEEE parity forbids FMA contraction",
+            }
+        result = {
+            "metric": "primary Mrays/s at 4K" if (W, H) == (3840, 2160) else f"primary Mrays/s at {W}x{H}",
+            "value": rays / (elapsed / args.steps) / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic: the reference's default scene (main.rs:154-193), first-frame pose, lightmaps from 4 radiosity bounces",
+            "config": {
+                "workload": f"default scene {W}x{H}, march + shading + texture + lightmap + reflections" + (" + FXAA" if args.fxaa else ""),
+                "width": W,
+                "height": H,
+                "bands": world,
+                "fxaa": bool(args.fxaa),
+                "map_size": 8,
+                "overlap_gather": world > 1 and not args.no_overlap,
+            },
+            "roofline": roofline,
+            "cap_hits": stats,
+        }
+        if not args.no_cpu_baseline:
+            lightmaps = [eng.get_lightmap(i) for i in range(eng.n_objects)]
+            base, cpu_rows = cpu_baseline(scene, lightmaps, W, H, args.cpu_seconds)
+            result["cpu_baseline"] = base
+            if not args.fxaa:
+                # the same frame from the GPU: a parity check at the benchmarked size
+                full = frames[(args.steps - 1) & 1] if world > 1 else None
+                if full is None:
+                    full = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+                    eng.render_rows_device(full.data_ptr(), 0, H)
+                    torch.cuda.synchronize()
+                gpu_rows = full[:H].cpu().numpy()
+                diff = np.abs(gpu_rows.astype(np.int16) - cpu_rows.astype(np.int16))
+                result["parity_vs_cpu_frame"] = {
+                    "max_abs_diff": int(diff.max()),
+                    "exact_pixel_fraction": float((diff.reshape(-1, 4).max(axis=1) == 0).mean()),
+                }
+        print(json.dumps(result), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

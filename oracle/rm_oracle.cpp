@@ -777,8 +777,9 @@ struct Engine {
         return rot(Vec3(u, v, p.zdepth), p.sx, p.cx, p.sy, p.cy).normalized();
     }
 
-    // engine.rs:38-127 over rows [row0, row1); `buffer` holds (row1-row0)*W*4 bytes.
-    void render_rows(uint8_t *buffer, int W, int H, int row0, int row1, const Pose &pose, int threads) {
+    // engine.rs:38-127 over rows row0, row0+row_step, ... < row1; `buffer` holds one
+    // W*4-byte row per rendered row (row_step > 1 is a sampling aid for timing).
+    void render_rows(uint8_t *buffer, int W, int H, int row0, int row1, int row_step, const Pose &pose, int threads) {
         Counters total;
 #ifdef _OPENMP
         if (threads <= 0) threads = omp_get_max_threads();
@@ -789,13 +790,13 @@ struct Engine {
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
 #endif
-            for (int y_inv = row0; y_inv < row1; y_inv++) {
+            for (int y_inv = row0; y_inv < row1; y_inv += row_step) {
                 for (int x = 0; x < W; x++) {
                     CNT(pixels, 1);
                     Vec3 dir = pixel_direction(pose, W, H, x, y_inv);
                     Colour colour_linear = cast_sight_ray(camera_position, dir, 0);
                     Colour colour_srgb = aces_film(colour_linear * pose.exposure).sqrt();  // engine.rs:110
-                    uint8_t *px = buffer + ((size_t)(y_inv - row0) * W + x) * 4;
+                    uint8_t *px = buffer + ((size_t)((y_inv - row0) / row_step) * W + x) * 4;
                     px[0] = to_pixel_range(colour_srgb.z());  // engine.rs:120-125
                     px[1] = to_pixel_range(colour_srgb.y());
                     px[2] = to_pixel_range(colour_srgb.x());
@@ -1164,11 +1165,12 @@ int orc_set_lightmap(void *h, int obj, const float *in) {
 }
 
 // Stateful render, as Engine::render: the camera moves by rot(rel_move).
-int orc_render(void *h, uint8_t *bgra, int W, int H, int row0, int row1, int mouse_x, int mouse_y,
+int orc_render(void *h, uint8_t *bgra, int W, int H, int row0, int row1, int row_step, int mouse_x, int mouse_y,
                const float *rel_move, int scroll, int threads) {
+    if (row_step < 1) row_step = 1;
     Engine *e = static_cast<Engine *>(h);
     Engine::Pose p = e->apply_input(mouse_x, mouse_y, Vec3(rel_move[0], rel_move[1], rel_move[2]), scroll);
-    e->render_rows(bgra, W, H, row0, row1, p, threads);
+    e->render_rows(bgra, W, H, row0, row1, row_step, p, threads);
     return 0;
 }
 

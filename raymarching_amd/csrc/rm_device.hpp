@@ -72,42 +72,159 @@ RM_DEV float sdf_eval(int type, float g0, float g1, float g2, float g3, V3 p) {
     }
 }
 
+// Correctly rounded square root.  v_sqrt_f32 is within one ulp; the two fused
+// residuals pick the correctly rounded neighbour, which is what the compiler's
+// own IEEE expansion does after rescaling its input.  Inputs that would need the
+// rescaling (below 2^-96), zeros, infinities, negatives and NaNs take that
+// full expansion instead.
+RM_DEV float sqrt_rn(float x) {
+    if (x >= 0x1p-96f && x < __builtin_inff()) {
+        float s = __builtin_amdgcn_sqrtf(x);
+        float sd = __int_as_float(__float_as_int(s) - 1);
+        float su = __int_as_float(__float_as_int(s) + 1);
+        float rd = __builtin_fmaf(-sd, s, x);
+        float ru = __builtin_fmaf(-su, s, x);
+        float r = (rd <= 0.0f) ? sd : s;
+        return (ru > 0.0f) ? su : r;
+    }
+    return sqrtf(x);
+}
+
 // ---------------------------------------------------------------------------
-// Scene access for the march loops.  `Small` is indexed by unrolled constants
-// out of the kernel arguments (scalar registers); `Large` walks global arrays
-// with wave-uniform addresses (scalar loads).
+// Scene access for the march loops: objects grouped by type.  `Small` is indexed
+// by unrolled constants out of the kernel arguments (scalar registers); `Large`
+// walks global arrays with wave-uniform addresses (scalar loads).
 // ---------------------------------------------------------------------------
 
+template <class G>
 struct SceneSmallAcc {
-    const SmallScene &s;
+    const G &g;
     template <class F>
-    RM_DEV void for_each(F &&f) const {
+    RM_DEV void spheres(F &&f) const {
 #pragma unroll
-        for (int i = 0; i < SMALL_SCENE; i++) {
-            if (i < s.n) f(i, s.type[i], s.geom[i].p[0], s.geom[i].p[1], s.geom[i].p[2], s.geom[i].p[3]);
-        }
+        for (int i = 0; i < G::kSpheres; i++)
+            if (i < g.n_sph) f(g.idx_sph[i], g.sph[i][0], g.sph[i][1], g.sph[i][2], g.sph[i][3]);
+    }
+    template <int AXIS, class F>
+    RM_DEV void axis(F &&f) const {
+        const int n = AXIS == 0 ? g.n_x : (AXIS == 1 ? g.n_y : g.n_z);
+#pragma unroll
+        for (int i = 0; i < G::kAxis; i++)
+            if (i < n) f(g.idx_ax[AXIS][i], g.ax[AXIS][i][0], g.ax[AXIS][i][1]);
+    }
+    template <class F>
+    RM_DEV void planes(F &&f) const {
+#pragma unroll
+        for (int i = 0; i < G::kPlanes; i++)
+            if (i < g.n_gp) f(g.idx_gp[i], g.gp[i][0], g.gp[i][1], g.gp[i][2], g.gp[i][3]);
     }
 };
 
 struct SceneLargeAcc {
-    int n;
-    const int *__restrict__ type;
-    const Geom *__restrict__ geom;
+    const GroupedLarge &g;
     template <class F>
-    RM_DEV void for_each(F &&f) const {
-        for (int i = 0; i < n; i++) {
-            Geom g = geom[i];
-            f(i, type[i], g.p[0], g.p[1], g.p[2], g.p[3]);
-        }
+    RM_DEV void spheres(F &&f) const {
+        for (int i = 0; i < g.n_sph; i++) f(g.idx_sph[i], g.sph[4 * i], g.sph[4 * i + 1], g.sph[4 * i + 2], g.sph[4 * i + 3]);
+    }
+    template <int AXIS, class F>
+    RM_DEV void axis(F &&f) const {
+        const int n = AXIS == 0 ? g.n_x : (AXIS == 1 ? g.n_y : g.n_z);
+        const int *idx = g.idx_ax[AXIS];
+        const float *a = g.ax[AXIS];
+        for (int i = 0; i < n; i++) f(idx[i], a[2 * i], a[2 * i + 1]);
+    }
+    template <class F>
+    RM_DEV void planes(F &&f) const {
+        for (int i = 0; i < g.n_gp; i++) f(g.idx_gp[i], g.gp[4 * i], g.gp[4 * i + 1], g.gp[4 * i + 2], g.gp[4 * i + 3]);
     }
 };
 
+template <int NS, int NA, int NG>
+RM_DEV SceneSmallAcc<GroupedSmall<NS, NA, NG>> acc_of(const GroupedSmall<NS, NA, NG> &g) {
+    return SceneSmallAcc<GroupedSmall<NS, NA, NG>>{g};
+}
+RM_DEV SceneLargeAcc acc_of(const GroupedLarge &g) { return SceneLargeAcc{g}; }
+
+// Which object a march leaves out (`ignore_object` of ray.rs:15,88).
+struct NoIgnore {
+    RM_DEV bool skip(int) const { return false; }
+    RM_DEV float mask(int, float s) const { return s; }
+};
+struct UniformIgnore {  // the same object in every lane: left out by a scalar branch
+    int u;
+    RM_DEV bool skip(int oi) const { return oi == u; }
+    RM_DEV float mask(int, float s) const { return s; }
+};
+struct LaneIgnore {  // differs between lanes: evaluated, then masked
+    int v;
+    RM_DEV bool skip(int) const { return false; }
+    RM_DEV float mask(int oi, float s) const { return oi == v ? __builtin_inff() : s; }
+};
+
+// min over objects of sdf(p): the value `distance` holds after the object loop
+// of ray.rs:23-33 / 98-107.
+//
+// A sphere whose distance provably cannot be below the running minimum skips
+// its square root: with T >= d + r and m >= T*T (both rounded upwards), the
+// correctly rounded sqrt(m) is >= T and sqrt(m) - r rounds to a value >= d.
+template <class SC, class IGN>
+RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign) {
+    float d = __builtin_inff();
+    sc.template axis<0>([&](int oi, float off, float dir) {
+        if (!ign.skip(oi)) d = rs_min(d, ign.mask(oi, dir * (p.x - off)));
+    });
+    sc.template axis<1>([&](int oi, float off, float dir) {
+        if (!ign.skip(oi)) d = rs_min(d, ign.mask(oi, dir * (p.y - off)));
+    });
+    sc.template axis<2>([&](int oi, float off, float dir) {
+        if (!ign.skip(oi)) d = rs_min(d, ign.mask(oi, dir * (p.z - off)));
+    });
+    sc.planes([&](int oi, float nx, float ny, float nz, float dist) {
+        if (!ign.skip(oi)) d = rs_min(d, ign.mask(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist));
+    });
+    sc.spheres([&](int oi, float cx, float cy, float cz, float r) {
+        if (ign.skip(oi)) return;
+        float m = mag_sqd(p - v3(cx, cy, cz));
+        float tu = (d + r) * 1.0000005f;
+        float q = (tu * tu) * 1.0000005f;
+        bool far = (tu > 1e-15f) && (m >= q);
+        if (!far) d = rs_min(d, ign.mask(oi, sqrt_rn(m) - r));
+    });
+    return d;
+}
+
+// Lowest object index whose sdf at p equals d (every object evaluated exactly).
+template <class SC, class IGN>
+RM_DEV int closest_index(const SC &sc, V3 p, float d, const IGN &ign) {
+    int best = 0x7fffffff;
+    auto take = [&](int oi, float s) {
+        if (ign.mask(oi, s) == d && oi < best) best = oi;
+    };
+    sc.template axis<0>([&](int oi, float off, float dir) {
+        if (!ign.skip(oi)) take(oi, dir * (p.x - off));
+    });
+    sc.template axis<1>([&](int oi, float off, float dir) {
+        if (!ign.skip(oi)) take(oi, dir * (p.y - off));
+    });
+    sc.template axis<2>([&](int oi, float off, float dir) {
+        if (!ign.skip(oi)) take(oi, dir * (p.z - off));
+    });
+    sc.planes([&](int oi, float nx, float ny, float nz, float dist) {
+        if (!ign.skip(oi)) take(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist);
+    });
+    sc.spheres([&](int oi, float cx, float cy, float cz, float r) {
+        if (!ign.skip(oi)) take(oi, sqrt_rn(mag_sqd(p - v3(cx, cy, cz))) - r);
+    });
+    return best == 0x7fffffff ? -1 : best;
+}
+
 // ray.rs:15-42 (and ray.rs:58-85: every object type collides, objects.rs:220,343).
-// `ignore` < 0 means None.  Returns the hit object or -1; `pos` ends where the
-// reference leaves Ray::position.
-template <class SC>
-RM_DEV int march(const SC &sc, V3 &pos, V3 dir, int ignore, int cap, int &steps, bool &capped) {
+// Returns the hit object or -1; `pos` ends where the reference leaves Ray::position.
+template <class SC, class IGN>
+RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, int &steps, bool &capped) {
     float travelled = 0.0f;
+    float d = 0.0f;
+    bool hit = false;
     steps = 0;
     capped = false;
     while (travelled < MAX_MARCH_DISTANCE) {
@@ -116,33 +233,37 @@ RM_DEV int march(const SC &sc, V3 &pos, V3 dir, int ignore, int cap, int &steps,
             return -1;
         }
         steps++;
-        float d = __builtin_inff();
-        int idx = -1;
-        sc.for_each([&](int i, int type, float g0, float g1, float g2, float g3) {
-            float s = sdf_eval(type, g0, g1, g2, g3, pos);
-            if (i != ignore && s < d) {
-                d = s;
-                idx = i;
-            }
-        });
-        if (d < SMALL_DISTANCE) return idx;
+        d = scene_min(sc, pos, ign);
+        if (d < SMALL_DISTANCE) {
+            hit = true;
+            break;
+        }
         travelled += d;
         pos = pos + dir * d;
     }
-    return -1;
+    return hit ? closest_index(sc, pos, d, ign) : -1;
+}
+
+// `ignore` < 0 means None.  A wave whose lanes all leave out the same object
+// (the usual case: neighbouring pixels hit the same surface) takes the variant
+// that drops it by a scalar branch.
+template <class SC>
+RM_DEV int march(const SC &sc, V3 &pos, V3 dir, int ignore, int cap, int &steps, bool &capped) {
+    const int u = __builtin_amdgcn_readfirstlane(ignore);
+    if (__all(ignore == u)) {
+        if (u < 0) return march_with(sc, pos, dir, NoIgnore{}, cap, steps, capped);
+        return march_with(sc, pos, dir, UniformIgnore{u}, cap, steps, capped);
+    }
+    return march_with(sc, pos, dir, LaneIgnore{ignore}, cap, steps, capped);
 }
 
 // ray.rs:87-118
-template <class SC>
-RM_DEV float smooth_shadow_march(const SC &sc, V3 pos, V3 dir, int ignore, float light_dist, float k) {
+template <class SC, class IGN>
+RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float light_dist, float k) {
     float travelled = 0.0f;
     float shade = 1.0f;
     for (int it = 0; it < MAX_SHAD_IT; it++) {
-        float d = __builtin_inff();
-        sc.for_each([&](int i, int type, float g0, float g1, float g2, float g3) {
-            float s = sdf_eval(type, g0, g1, g2, g3, pos);
-            if (i != ignore && s < d) d = s;
-        });
+        float d = scene_min(sc, pos, ign);
         float x = rs_clamp(k * d / travelled, 0.0f, 1.0f);
         float ss = 3.0f * (x * x) - 2.0f * (x * (x * x));
         shade = rs_min(shade, ss);
@@ -151,6 +272,13 @@ RM_DEV float smooth_shadow_march(const SC &sc, V3 pos, V3 dir, int ignore, float
         if (d < SMALL_DISTANCE || travelled > light_dist) break;
     }
     return rs_clamp(shade, 0.0f, 1.0f);
+}
+
+template <class SC>
+RM_DEV float smooth_shadow_march(const SC &sc, V3 pos, V3 dir, int ignore, float light_dist, float k) {
+    const int u = __builtin_amdgcn_readfirstlane(ignore);
+    if (__all(ignore == u)) return shadow_with(sc, pos, dir, UniformIgnore{u}, light_dist, k);
+    return shadow_with(sc, pos, dir, LaneIgnore{ignore}, light_dist, k);
 }
 
 // objects.rs:135-141 for a per-lane object
@@ -194,8 +322,17 @@ RM_DEV void sample_uv_from_pos(int type, const Geom &g, V3 pos, float ms, float 
 
 // texture.rs:31-37
 RM_DEV V3 texture_sample(const TextureRec &t, float u, float v) {
-    float fx = fmodf(floorf(fabsf(u * t.uscale)), (float)t.w);
-    float fy = fmodf(floorf(fabsf(v * t.vscale)), (float)t.h);
+    float ax = floorf(fabsf(u * t.uscale)), ay = floorf(fabsf(v * t.vscale));
+    float fw = (float)t.w, fh = (float)t.h;
+    float fx, fy;
+    if (t.pow2) {
+        // x mod 2^k for a non-negative integer-valued x: every step below is exact
+        fx = ax - fw * floorf(ax / fw);
+        fy = ay - fh * floorf(ay / fh);
+    } else {
+        fx = fmodf(ax, fw);
+        fy = fmodf(ay, fh);
+    }
     int x = sat_i32(fx), y = sat_i32(fy);
     x = min(x, t.w - 1);  // fmod keeps both below w/h; NaN maps to 0
     y = min(y, t.h - 1);
@@ -296,10 +433,15 @@ RM_DEV void phong_ds(V3 n, V3 l, float dist, float intensity, const ShadeRec &m,
     V3 r = reflect(l, n);
     float li = intensity / (dist * dist);
     diffuse = m.diffuse * li * rs_max(dot(l, n), 0.0f);
-    if (diffuse > 0.0f)
-        specular = m.specular * li * powf(rs_max(dot(r, view), 0.0f), m.shininess);
-    else
-        specular = 0.0f;
+    specular = 0.0f;
+    if (diffuse > 0.0f) {
+        float base = rs_max(dot(r, view), 0.0f);
+        // 0 * li * powf(base, shininess) is +0 whenever li and the power are finite
+        // and positive; only then is the call left out.
+        bool zero = (m.specular == 0.0f) && (m.shininess >= 0.0f) && (li > 0.0f) && (li < __builtin_inff()) &&
+                    (base < __builtin_inff());
+        if (!zero) specular = m.specular * li * powf(base, m.shininess);
+    }
 }
 
 struct ShadeResult {

@@ -32,7 +32,7 @@ constexpr int BLOCK_W = TILE * BLOCK_TILES_X, BLOCK_H = TILE * BLOCK_TILES_Y;
 constexpr int BLOCK_THREADS = 64 * BLOCK_TILES_X * BLOCK_TILES_Y;
 
 struct RenderArgs {
-    SceneView sv;
+    const SceneView *sv;  // device memory: read where needed, not held in registers
     Pose pose;
     int row_begin, row_end;
     int blocks_x;
@@ -48,43 +48,30 @@ __device__ __forceinline__ void tile_pixel(int blocks_x, int row_begin, int &x, 
 }
 
 // engine.rs:77-126 fused: direction, cast_sight_ray, tone map, pack.
-template <bool SMALL>
-__global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderArgs a, const SmallScene small) {
+template <class G>
+__global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderArgs a, const G g) {
     int x, y_inv;
     tile_pixel(a.blocks_x, a.row_begin, x, y_inv);
     if (x >= a.pose.W || y_inv >= a.row_end) return;
     V3 dir = pixel_direction(a.pose, x, y_inv);
     V3 cam = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
-    V3 colour;
-    if constexpr (SMALL) {
-        SceneSmallAcc sc{small};
-        colour = cast_sight_ray(sc, a.sv, cam, dir);
-    } else {
-        SceneLargeAcc sc{a.sv.n, a.sv.type, a.sv.geom};
-        colour = cast_sight_ray(sc, a.sv, cam, dir);
-    }
+    V3 colour = cast_sight_ray(acc_of(g), *a.sv, cam, dir);
     unsigned px = pack_pixel(colour, a.pose.exposure);
     *reinterpret_cast<unsigned *>(a.out + (size_t)(y_inv - a.row_begin) * a.pitch + (size_t)x * 4) = px;
 }
 
 // Primary march only: hit object, iteration count, final position.
-template <bool SMALL>
-__global__ __launch_bounds__(BLOCK_THREADS) void trace_kernel(const RenderArgs a, const SmallScene small, int *hit,
-                                                              int *steps_out, float *pos_out) {
+template <class G>
+__global__ __launch_bounds__(BLOCK_THREADS) void trace_kernel(const RenderArgs a, int *hit, int *steps_out,
+                                                              float *pos_out, const G g) {
     int x, y_inv;
     tile_pixel(a.blocks_x, a.row_begin, x, y_inv);
     if (x >= a.pose.W || y_inv >= a.row_end) return;
     V3 dir = pixel_direction(a.pose, x, y_inv);
     V3 pos = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
-    int steps, idx;
+    int steps;
     bool capped;
-    if constexpr (SMALL) {
-        SceneSmallAcc sc{small};
-        idx = march(sc, pos, dir, -1, a.sv.march_cap, steps, capped);
-    } else {
-        SceneLargeAcc sc{a.sv.n, a.sv.type, a.sv.geom};
-        idx = march(sc, pos, dir, -1, a.sv.march_cap, steps, capped);
-    }
+    int idx = march(acc_of(g), pos, dir, -1, a.sv->march_cap, steps, capped);
     size_t i = (size_t)y_inv * a.pose.W + x;
     if (hit) hit[i] = idx;
     if (steps_out) steps_out[i] = steps;
@@ -96,11 +83,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_kernel(const RenderArgs a
 }
 
 // Engine::shade_object at arbitrary points (engine.rs:147-244).
-template <bool SMALL>
-__global__ void probe_shade_kernel(const SceneView sv, const SmallScene small, int n, const int *obj, const float *pos,
-                                   const float *dir, float *out) {
+template <class G>
+__global__ void probe_shade_kernel(const SceneView *svp, int n, const int *obj, const float *pos, const float *dir,
+                                   float *out, const G g) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const SceneView &sv = *svp;
     V3 p = v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
     V3 d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
     int idx = obj[i];
@@ -117,16 +105,13 @@ __global__ void probe_shade_kernel(const SceneView sv, const SmallScene small, i
         out[3 * i + 1] = c.y;
         out[3 * i + 2] = c.z;
     };
-    if constexpr (SMALL)
-        body(SceneSmallAcc{small});
-    else
-        body(SceneLargeAcc{sv.n, sv.type, sv.geom});
+    body(acc_of(g));
 }
 
 // ---- radiosity -------------------------------------------------------------
 
 struct RadArgs {
-    SceneView sv;
+    const SceneView *sv;
     int n_patches;          // n_lm * M * M
     const int *patch_obj;   // [n_lm] engine index of each cloud object
     const float *pos;       // [NP][3] point cloud (engine.rs:272)
@@ -142,12 +127,12 @@ struct RadArgs {
 __global__ void rad_cloud_kernel(const RadArgs a) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.n_patches) return;
-    const int mm = a.sv.map_size * a.sv.map_size;
+    const int mm = a.sv->map_size * a.sv->map_size;
     int obj = a.patch_obj[p / mm];
     V3 pos = v3(a.pos[3 * p], a.pos[3 * p + 1], a.pos[3 * p + 2]);
-    const ShadeRec sr = a.sv.shade[obj];
-    const Geom g = a.sv.geom[obj];
-    V3 c = object_colour(a.sv, sr, g, pos);
+    const ShadeRec sr = a.sv->shade[obj];
+    const Geom g = a.sv->geom[obj];
+    V3 c = object_colour(*a.sv, sr, g, pos);
     V3 n = calculate_normal(sr.type, g, pos);
     a.col[3 * p] = c.x;
     a.col[3 * p + 1] = c.y;
@@ -158,31 +143,28 @@ __global__ void rad_cloud_kernel(const RadArgs a) {
 }
 
 // radiosity.rs:52-101
-template <bool SMALL>
-__global__ void rad_direct_kernel(const RadArgs a, const SmallScene small) {
+template <class G>
+__global__ void rad_direct_kernel(const RadArgs a, const G grp) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.n_patches) return;
-    const int mm = a.sv.map_size * a.sv.map_size;
+    const int mm = a.sv->map_size * a.sv->map_size;
     int obj = a.patch_obj[p / mm];
-    const ShadeRec sr = a.sv.shade[obj];
-    const Geom g = a.sv.geom[obj];
+    const ShadeRec sr = a.sv->shade[obj];
+    const Geom g = a.sv->geom[obj];
     V3 origin = v3(a.pos[3 * p], a.pos[3 * p + 1], a.pos[3 * p + 2]);
     V3 colour = v3(a.col[3 * p], a.col[3 * p + 1], a.col[3 * p + 2]);
-    V3 light = v3(a.sv.light[0], a.sv.light[1], a.sv.light[2]);
+    V3 light = v3(a.sv->light[0], a.sv->light[1], a.sv->light[2]);
     V3 to_light = light - origin;
     float dist = mag(to_light);
     to_light = to_light / dist;
     V3 rp = origin;
     int steps;
     bool capped;
-    if constexpr (SMALL)
-        march(SceneSmallAcc{small}, rp, to_light, obj, 0, steps, capped);
-    else
-        march(SceneLargeAcc{a.sv.n, a.sv.type, a.sv.geom}, rp, to_light, obj, 0, steps, capped);
+    march(acc_of(grp), rp, to_light, obj, 0, steps, capped);
     V3 em = v3(0.0f, 0.0f, 0.0f), lm = v3(0.0f, 0.0f, 0.0f);
     if (!(mag(rp - origin) < (dist + 3.0f * SMALL_DISTANCE))) {
         V3 n = calculate_normal(sr.type, g, origin);
-        float diffuse = rs_max(dot(n, to_light), 0.0f) * a.sv.intensity / (dist * dist);
+        float diffuse = rs_max(dot(n, to_light), 0.0f) * a.sv->intensity / (dist * dist);
         em = colour * (diffuse + sr.emissive);
         lm = colour * sr.emissive;
     }
@@ -196,12 +178,12 @@ __global__ void rad_direct_kernel(const RadArgs a, const SmallScene small) {
 
 // radiosity.rs:119-152 for one (receiver i, source j) pair: everything of the
 // inner loop that does not depend on the bounce.  x = receiver, y = source.
-template <bool SMALL>
-__global__ void rad_form_kernel(const RadArgs a, const SmallScene small, int p0, int p1) {
+template <class G>
+__global__ void rad_form_kernel(const RadArgs a, int p0, int p1, const G grp) {
     int i = p0 + blockIdx.x * blockDim.x + threadIdx.x;
     int j = blockIdx.y;
     if (i >= p1) return;
-    const int mm = a.sv.map_size * a.sv.map_size;
+    const int mm = a.sv->map_size * a.sv->map_size;
     float f = -1.0f;
     if (i / mm != j / mm) {  // radiosity.rs:112: no self illumination
         int recv_obj = a.patch_obj[i / mm];
@@ -214,12 +196,9 @@ __global__ void rad_form_kernel(const RadArgs a, const SmallScene small, int p0,
         to_light = to_light / dist;
         V3 back = -to_light;
         V3 rp = src + back * (3.0f * SMALL_DISTANCE);  // radiosity.rs:131
-        int steps, hit;
+        int steps;
         bool capped;
-        if constexpr (SMALL)
-            hit = march(SceneSmallAcc{small}, rp, back, -1, 0, steps, capped);
-        else
-            hit = march(SceneLargeAcc{a.sv.n, a.sv.type, a.sv.geom}, rp, back, -1, 0, steps, capped);
+        int hit = march(acc_of(grp), rp, back, -1, 0, steps, capped);
         bool blocked = (hit >= 0) && (hit != recv_obj) && (mag_sqd(rp - sample_pos) > 0.1f * 0.1f);
         if (!blocked) {
             float att = dot(sample_n, to_light) * -dot(src_n, to_light);
@@ -371,8 +350,14 @@ struct rm_engine {
 
     // device-resident scene
     int n = 0, n_lm = 0, n_patches = 0;
-    bool small = false;
-    SmallScene small_scene;
+    int tier = 2;  // 0: GroupedTierA, 1: GroupedTierB, 2: GroupedLarge
+    GroupedTierA tier_a;
+    GroupedTierB tier_b;
+    GroupedLarge large_scene;
+    SceneView h_view;            // host copy of the device-resident SceneView
+    SceneView *d_view = nullptr;
+    bool view_dirty = true;
+    std::vector<void *> d_group_arrays;
     std::vector<int> lm_slot;    // per object, -1 = none
     std::vector<int> patch_obj;  // per lightmap slot: engine index
     int *d_type = nullptr;
@@ -411,7 +396,7 @@ struct rm_engine {
     }
     RadArgs rad_args() const {
         RadArgs a;
-        a.sv = view();
+        a.sv = d_view;
         a.n_patches = n_patches;
         a.patch_obj = d_patch_obj;
         a.pos = d_pos;
@@ -469,14 +454,14 @@ static hipError_t dev_alloc(T **p, size_t count) {
 static int engine_upload(rm_engine *e) {
     const rm_scene &s = e->scene;
     e->n = (int)s.objects.size();
-    e->small = e->n <= SMALL_SCENE;
     std::vector<int> type(e->n);
     std::vector<Geom> geom(e->n);
     std::vector<ShadeRec> shade(e->n);
     e->lm_slot.assign(e->n, -1);
     e->patch_obj.clear();
-    memset(&e->small_scene, 0, sizeof(SmallScene));
-    e->small_scene.n = e->small ? e->n : 0;
+    // objects grouped by type for the march loops (original indices kept alongside)
+    std::vector<int> gi_sph, gi_ax[3], gi_gp;
+    std::vector<float> g_sph, g_ax[3], g_gp;
     for (int i = 0; i < e->n; i++) {
         const HostObject &o = s.objects[i];
         type[i] = o.type;
@@ -503,10 +488,93 @@ static int engine_upload(rm_engine *e) {
             r.lm_slot = -1;
         }
         shade[i] = r;
-        if (e->small) {
-            e->small_scene.type[i] = o.type;
-            memcpy(e->small_scene.geom[i].p, o.p, sizeof(float) * 4);
+        switch (o.type) {
+            case T_SPHERE:
+                gi_sph.push_back(i);
+                g_sph.insert(g_sph.end(), o.p, o.p + 4);
+                break;
+            case T_XPLANE:
+            case T_YPLANE:
+            case T_ZPLANE: {
+                int a = o.type - T_XPLANE;
+                gi_ax[a].push_back(i);
+                g_ax[a].insert(g_ax[a].end(), o.p, o.p + 2);
+                break;
+            }
+            default:
+                gi_gp.push_back(i);
+                g_gp.insert(g_gp.end(), o.p, o.p + 4);
+                break;
         }
+    }
+    auto fits = [&](int ns, int na, int ng) {
+        return (int)gi_sph.size() <= ns && (int)gi_ax[0].size() <= na && (int)gi_ax[1].size() <= na &&
+               (int)gi_ax[2].size() <= na && (int)gi_gp.size() <= ng;
+    };
+    auto fill = [&](auto &gs) {
+        memset(&gs, 0, sizeof(gs));
+        gs.n_sph = (int)gi_sph.size();
+        gs.n_x = (int)gi_ax[0].size();
+        gs.n_y = (int)gi_ax[1].size();
+        gs.n_z = (int)gi_ax[2].size();
+        gs.n_gp = (int)gi_gp.size();
+        for (size_t k = 0; k < gi_sph.size(); k++) {
+            gs.idx_sph[k] = gi_sph[k];
+            memcpy(gs.sph[k], &g_sph[4 * k], sizeof(float) * 4);
+        }
+        for (int a = 0; a < 3; a++)
+            for (size_t k = 0; k < gi_ax[a].size(); k++) {
+                gs.idx_ax[a][k] = gi_ax[a][k];
+                memcpy(gs.ax[a][k], &g_ax[a][2 * k], sizeof(float) * 2);
+            }
+        for (size_t k = 0; k < gi_gp.size(); k++) {
+            gs.idx_gp[k] = gi_gp[k];
+            memcpy(gs.gp[k], &g_gp[4 * k], sizeof(float) * 4);
+        }
+    };
+    memset(&e->tier_a, 0, sizeof(e->tier_a));
+    memset(&e->tier_b, 0, sizeof(e->tier_b));
+    if (fits(GroupedTierA::kSpheres, GroupedTierA::kAxis, GroupedTierA::kPlanes)) {
+        e->tier = 0;
+        fill(e->tier_a);
+    } else if (fits(GroupedTierB::kSpheres, GroupedTierB::kAxis, GroupedTierB::kPlanes)) {
+        e->tier = 1;
+        fill(e->tier_b);
+    } else {
+        e->tier = 2;
+    }
+    {
+        GroupedLarge &gl = e->large_scene;
+        memset(&gl, 0, sizeof(gl));
+        gl.n_sph = (int)gi_sph.size();
+        gl.n_x = (int)gi_ax[0].size();
+        gl.n_y = (int)gi_ax[1].size();
+        gl.n_z = (int)gi_ax[2].size();
+        gl.n_gp = (int)gi_gp.size();
+        auto up_i = [&](const std::vector<int> &v, const int **dst) -> hipError_t {
+            int *d = nullptr;
+            hipError_t err = dev_alloc(&d, v.size());
+            if (err != hipSuccess) return err;
+            e->d_group_arrays.push_back(d);
+            *dst = d;
+            return v.empty() ? hipSuccess : hipMemcpy(d, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice);
+        };
+        auto up_f = [&](const std::vector<float> &v, const float **dst) -> hipError_t {
+            float *d = nullptr;
+            hipError_t err = dev_alloc(&d, v.size());
+            if (err != hipSuccess) return err;
+            e->d_group_arrays.push_back(d);
+            *dst = d;
+            return v.empty() ? hipSuccess : hipMemcpy(d, v.data(), sizeof(float) * v.size(), hipMemcpyHostToDevice);
+        };
+        HIP_TRY(up_i(gi_sph, &gl.idx_sph));
+        HIP_TRY(up_f(g_sph, &gl.sph));
+        for (int a = 0; a < 3; a++) {
+            HIP_TRY(up_i(gi_ax[a], &gl.idx_ax[a]));
+            HIP_TRY(up_f(g_ax[a], &gl.ax[a]));
+        }
+        HIP_TRY(up_i(gi_gp, &gl.idx_gp));
+        HIP_TRY(up_f(g_gp, &gl.gp));
     }
     e->n_lm = (int)e->patch_obj.size();
     e->n_patches = e->n_lm * e->M * e->M;
@@ -524,13 +592,16 @@ static int engine_upload(rm_engine *e) {
         const HostTexture &ht = s.textures[t];
         HIP_TRY(dev_alloc(&e->d_texels[t], ht.texels.size()));
         HIP_TRY(hipMemcpy(e->d_texels[t], ht.texels.data(), sizeof(float) * ht.texels.size(), hipMemcpyHostToDevice));
-        tex[t] = TextureRec{e->d_texels[t], ht.w, ht.h, ht.uscale, ht.vscale};
+        const bool pow2 = (ht.w & (ht.w - 1)) == 0 && (ht.h & (ht.h - 1)) == 0;
+        tex[t] = TextureRec{e->d_texels[t], ht.w, ht.h, ht.uscale, ht.vscale, pow2 ? 1 : 0, 0};
     }
     HIP_TRY(dev_alloc(&e->d_tex, tex.size()));
     if (!tex.empty()) HIP_TRY(hipMemcpy(e->d_tex, tex.data(), sizeof(TextureRec) * tex.size(), hipMemcpyHostToDevice));
 
     HIP_TRY(dev_alloc(&e->d_lightmaps, (size_t)e->n_patches * 3));
     HIP_TRY(hipMemset(e->d_lightmaps, 0, std::max<size_t>((size_t)e->n_patches * 3, 1) * sizeof(float)));
+    HIP_TRY(dev_alloc(&e->d_view, 1));
+    e->view_dirty = true;
     HIP_TRY(dev_alloc(&e->d_stats, RM_STAT_COUNT));
     HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * RM_STAT_COUNT));
     HIP_TRY(dev_alloc(&e->d_patch_obj, e->n_lm));
@@ -548,6 +619,7 @@ static void engine_free(rm_engine *e) {
     for (float *p : e->d_texels) (void)hipFree(p);
     (void)hipFree(e->d_lightmaps);
     (void)hipFree(e->d_stats);
+    (void)hipFree(e->d_view);
     (void)hipFree(e->d_frame);
     (void)hipFree(e->d_patch_obj);
     (void)hipFree(e->d_pos);
@@ -556,11 +628,34 @@ static void engine_free(rm_engine *e) {
     (void)hipFree(e->d_emissive);
     (void)hipFree(e->d_emissive_next);
     (void)hipFree(e->d_ft);
+    for (void *p : e->d_group_arrays) (void)hipFree(p);
+}
+
+// Launches KERNEL<G>(args..., grouped scene) for the engine's scene tier.
+#define RM_LAUNCH(KERNEL, e, grid, block, ...)                                                                \
+    do {                                                                                                      \
+        if ((e)->tier == 0)                                                                                   \
+            hipLaunchKernelGGL((KERNEL<GroupedTierA>), grid, block, 0, (e)->stream, __VA_ARGS__, (e)->tier_a); \
+        else if ((e)->tier == 1)                                                                              \
+            hipLaunchKernelGGL((KERNEL<GroupedTierB>), grid, block, 0, (e)->stream, __VA_ARGS__, (e)->tier_b); \
+        else                                                                                                  \
+            hipLaunchKernelGGL((KERNEL<GroupedLarge>), grid, block, 0, (e)->stream, __VA_ARGS__,              \
+                               (e)->large_scene);                                                             \
+    } while (0)
+
+// Brings the device copy of the SceneView up to date (stream ordered).
+static int sync_view(rm_engine *e) {
+    if (!e->view_dirty) return RM_OK;
+    e->h_view = e->view();
+    HIP_TRY(hipMemcpyAsync(e->d_view, &e->h_view, sizeof(SceneView), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // h_view may change before an async copy would read it
+    e->view_dirty = false;
+    return RM_OK;
 }
 
 static RenderArgs make_render_args(rm_engine *e, void *d_out, size_t pitch, int row_begin, int row_end, dim3 &grid) {
     RenderArgs a;
-    a.sv = e->view();
+    a.sv = e->d_view;
     a.pose = e->pose;
     a.row_begin = row_begin;
     a.row_end = row_end;
@@ -750,12 +845,10 @@ int rm_engine_render_rows_device(rm_engine *e, void *d_bgra, size_t pitch_bytes,
     if (pitch_bytes < (size_t)e->W * 4 || (pitch_bytes & 3)) return fail(RM_ERR_INVALID, "pitch must be >= width*4 and a multiple of 4");
     if (row_begin == row_end) return RM_OK;
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     dim3 grid;
     RenderArgs a = make_render_args(e, d_bgra, pitch_bytes, row_begin, row_end, grid);
-    if (e->small)
-        hipLaunchKernelGGL(render_kernel<true>, grid, dim3(BLOCK_THREADS), 0, e->stream, a, e->small_scene);
-    else
-        hipLaunchKernelGGL(render_kernel<false>, grid, dim3(BLOCK_THREADS), 0, e->stream, a, e->small_scene);
+    RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);
     HIP_TRY(hipGetLastError());
     return RM_OK;
 }
@@ -767,6 +860,7 @@ int rm_engine_render(rm_engine *e, uint8_t *bgra, size_t pitch_bytes, int32_t mo
     int rc = rm_engine_input(e, mouse_x, mouse_y, rel_move, scroll);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     if (!e->d_frame) HIP_TRY(dev_alloc(&e->d_frame, (size_t)e->W * e->H * 4));
     rc = rm_engine_render_rows_device(e, e->d_frame, (size_t)e->W * 4, 0, e->H);
     if (rc) return rc;
@@ -782,6 +876,7 @@ int rm_engine_fxaa_device(rm_engine *e, const void *d_src, void *d_dst, int row_
     if (row_begin < 0 || row_end > e->H || row_begin > row_end) return fail(RM_ERR_INVALID, "row range outside the frame");
     if (row_begin == row_end) return RM_OK;
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     dim3 grid((e->W + 63) / 64, (row_end - row_begin + 3) / 4);
     hipLaunchKernelGGL(fxaa_kernel, grid, dim3(256), 0, e->stream, static_cast<const unsigned char *>(d_src),
                        static_cast<unsigned char *>(d_dst), e->W, e->H, row_begin, row_end);
@@ -792,6 +887,7 @@ int rm_engine_fxaa_device(rm_engine *e, const void *d_src, void *d_dst, int row_
 int rm_engine_trace_primary(rm_engine *e, int32_t *hit, int32_t *steps, float *position) {
     if (!e) return fail(RM_ERR_INVALID, "NULL engine");
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     size_t npx = (size_t)e->W * e->H;
     int *d_hit = nullptr, *d_steps = nullptr;
     float *d_pos = nullptr;
@@ -800,12 +896,7 @@ int rm_engine_trace_primary(rm_engine *e, int32_t *hit, int32_t *steps, float *p
     HIP_TRY(dev_alloc(&d_pos, npx * 3));
     dim3 grid;
     RenderArgs a = make_render_args(e, d_hit, (size_t)e->W * 4, 0, e->H, grid);
-    if (e->small)
-        hipLaunchKernelGGL(trace_kernel<true>, grid, dim3(BLOCK_THREADS), 0, e->stream, a, e->small_scene, d_hit,
-                           d_steps, d_pos);
-    else
-        hipLaunchKernelGGL(trace_kernel<false>, grid, dim3(BLOCK_THREADS), 0, e->stream, a, e->small_scene, d_hit,
-                           d_steps, d_pos);
+    RM_LAUNCH(trace_kernel, e, grid, dim3(BLOCK_THREADS), a, d_hit, d_steps, d_pos);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
     if (err == hipSuccess && hit) err = hipMemcpy(hit, d_hit, npx * sizeof(int), hipMemcpyDeviceToHost);
@@ -825,6 +916,7 @@ int rm_engine_probe_shade(rm_engine *e, int n, const int32_t *object, const floa
     for (int i = 0; i < n; i++)
         if (object[i] < 0 || object[i] >= e->n) return fail(RM_ERR_INVALID, "object index out of range");
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     int *d_obj = nullptr;
     float *d_pos = nullptr, *d_dir = nullptr, *d_out = nullptr;
     HIP_TRY(dev_alloc(&d_obj, n));
@@ -836,12 +928,8 @@ int rm_engine_probe_shade(rm_engine *e, int n, const int32_t *object, const floa
     if (err == hipSuccess) err = hipMemcpy(d_dir, direction, sizeof(float) * 3 * n, hipMemcpyHostToDevice);
     if (err == hipSuccess) {
         dim3 grid((n + 63) / 64);
-        if (e->small)
-            hipLaunchKernelGGL(probe_shade_kernel<true>, grid, dim3(64), 0, e->stream, e->view(), e->small_scene, n,
-                               d_obj, d_pos, d_dir, d_out);
-        else
-            hipLaunchKernelGGL(probe_shade_kernel<false>, grid, dim3(64), 0, e->stream, e->view(), e->small_scene, n,
-                               d_obj, d_pos, d_dir, d_out);
+        RM_LAUNCH(probe_shade_kernel, e, grid, dim3(64), (const SceneView *)e->d_view, n, (const int *)d_obj,
+                  (const float *)d_pos, (const float *)d_dir, d_out);
         err = hipGetLastError();
     }
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
@@ -859,6 +947,7 @@ int rm_engine_probe_shade(rm_engine *e, int n, const int32_t *object, const floa
 int rm_engine_radiosity_begin(rm_engine *e) {
     if (!e) return fail(RM_ERR_INVALID, "NULL engine");
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     const int NP = e->n_patches, M = e->M;
     if (!e->d_pos) {
         HIP_TRY(dev_alloc(&e->d_pos, (size_t)NP * 3));
@@ -884,10 +973,7 @@ int rm_engine_radiosity_begin(rm_engine *e) {
     RadArgs a = e->rad_args();
     dim3 grid((NP + 63) / 64);
     hipLaunchKernelGGL(rad_cloud_kernel, grid, dim3(64), 0, e->stream, a);
-    if (e->small)
-        hipLaunchKernelGGL(rad_direct_kernel<true>, grid, dim3(64), 0, e->stream, a, e->small_scene);
-    else
-        hipLaunchKernelGGL(rad_direct_kernel<false>, grid, dim3(64), 0, e->stream, a, e->small_scene);
+    RM_LAUNCH(rad_direct_kernel, e, grid, dim3(64), a);
     HIP_TRY(hipGetLastError());
     return RM_OK;
 }
@@ -903,16 +989,14 @@ int rm_engine_radiosity_form_factors(rm_engine *e, int p0, int p1) {
     int rc = check_patch_range(e, p0, p1);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     const int NP = e->n_patches;
     if (!e->d_ft) HIP_TRY(dev_alloc(&e->d_ft, (size_t)NP * NP));
     if (p0 == p1) return RM_OK;
     if (NP > 65535) return fail(RM_ERR_LIMIT, "more than 65535 patches");
     RadArgs a = e->rad_args();
     dim3 grid((p1 - p0 + 63) / 64, NP);
-    if (e->small)
-        hipLaunchKernelGGL(rad_form_kernel<true>, grid, dim3(64), 0, e->stream, a, e->small_scene, p0, p1);
-    else
-        hipLaunchKernelGGL(rad_form_kernel<false>, grid, dim3(64), 0, e->stream, a, e->small_scene, p0, p1);
+    RM_LAUNCH(rad_form_kernel, e, grid, dim3(64), a, p0, p1);
     HIP_TRY(hipGetLastError());
     return RM_OK;
 }
@@ -923,6 +1007,7 @@ int rm_engine_radiosity_bounce(rm_engine *e, int p0, int p1) {
     if (!e->d_ft) return fail(RM_ERR_INVALID, "call rm_engine_radiosity_form_factors first");
     if (p0 == p1) return RM_OK;
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     RadArgs a = e->rad_args();
     dim3 grid((p1 - p0 + 63) / 64);
     hipLaunchKernelGGL(rad_bounce_kernel, grid, dim3(64), 0, e->stream, a, p0, p1);
@@ -933,6 +1018,7 @@ int rm_engine_radiosity_bounce(rm_engine *e, int p0, int p1) {
 int rm_engine_radiosity_commit(rm_engine *e) {
     if (!e || !e->rad_begun) return fail(RM_ERR_INVALID, "radiosity not begun");
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     if (e->n_patches)
         HIP_TRY(hipMemcpyAsync(e->d_emissive, e->d_emissive_next, sizeof(float) * 3 * e->n_patches,
                                hipMemcpyDeviceToDevice, e->stream));
@@ -970,6 +1056,7 @@ int rm_engine_get_lightmap(rm_engine *e, int object, float *values) {
     int slot = e->lm_slot[object];
     if (slot < 0) return fail(RM_ERR_UNSUPPORTED, "object has no lightmap");
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     size_t count = (size_t)e->M * e->M * 3;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(values, e->d_lightmaps + slot * count, count * sizeof(float), hipMemcpyDeviceToHost));
@@ -981,6 +1068,7 @@ int rm_engine_set_lightmap(rm_engine *e, int object, const float *values) {
     int slot = e->lm_slot[object];
     if (slot < 0) return fail(RM_ERR_UNSUPPORTED, "object has no lightmap");
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     size_t count = (size_t)e->M * e->M * 3;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->d_lightmaps + slot * count, values, count * sizeof(float), hipMemcpyHostToDevice));
@@ -990,12 +1078,14 @@ int rm_engine_set_lightmap(rm_engine *e, int object, const float *values) {
 int rm_engine_set_march_cap(rm_engine *e, int max_steps) {
     if (!e || max_steps < 0) return fail(RM_ERR_INVALID, "bad argument");
     e->march_cap = max_steps;
+    e->view_dirty = true;
     return RM_OK;
 }
 
 int rm_engine_get_stats(rm_engine *e, uint64_t stats[RM_STAT_COUNT]) {
     if (!e || !stats) return fail(RM_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(stats, e->d_stats, sizeof(uint64_t) * RM_STAT_COUNT, hipMemcpyDeviceToHost));
     return RM_OK;
@@ -1003,6 +1093,7 @@ int rm_engine_get_stats(rm_engine *e, uint64_t stats[RM_STAT_COUNT]) {
 int rm_engine_reset_stats(rm_engine *e) {
     if (!e) return fail(RM_ERR_INVALID, "NULL engine");
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     HIP_TRY(hipMemsetAsync(e->d_stats, 0, sizeof(uint64_t) * RM_STAT_COUNT, e->stream));
     return RM_OK;
 }
@@ -1010,6 +1101,7 @@ int rm_engine_reset_stats(rm_engine *e) {
 int rm_engine_synchronize(rm_engine *e) {
     if (!e) return fail(RM_ERR_INVALID, "NULL engine");
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
     HIP_TRY(hipStreamSynchronize(e->stream));
     return RM_OK;
 }

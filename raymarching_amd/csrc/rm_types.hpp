@@ -15,8 +15,7 @@ constexpr float STEP_SIZE = 0.0001f;
 // engine.rs:192
 constexpr float SHADOW_K = 16.0f;
 
-constexpr int MAX_DEPTH = 16;    // explicit reflection stack (the reference recurses without bound)
-constexpr int SMALL_SCENE = 16;  // scenes up to this size travel in the kernel arguments (SGPRs)
+constexpr int MAX_DEPTH = 16;  // explicit reflection stack (the reference recurses without bound)
 
 // Geometry of one object, 16 bytes.
 //   sphere      : cx, cy, cz, radius
@@ -42,14 +41,41 @@ struct TextureRec {
     const float *texels;  // [h][w][4] floats, rgb already squared as rgb! does (colour.rs:7-15)
     int w, h;
     float uscale, vscale;
+    int pow2;  // w and h are powers of two: the wrap of texture.rs:32-33 needs no fmod
+    int pad;
 };
 
-// A scene small enough to be passed by value: the march loops index it with
-// compile-time constants, so every field lives in scalar registers.
-struct SmallScene {
-    int n;
-    int type[SMALL_SCENE];
-    Geom geom[SMALL_SCENE];
+// The march loops see the scene grouped by primitive type, so that they run
+// without a per-object type dispatch.  The minimum over objects does not depend
+// on the order; the index of the closest object (lowest index on ties, as the
+// strict `<` of ray.rs:29) is recovered from `index` once a march has ended.
+//
+// A scene within the bounds <NS, NA, NG> (spheres, planes per axis, generic
+// planes) is passed by value in the kernel arguments: every field is then
+// addressed by a compile-time constant and lives in scalar registers.  Two tiers
+// are built; larger scenes use the same layout in global memory (GroupedLarge).
+template <int NS, int NA, int NG>
+struct GroupedSmall {
+    static constexpr int kSpheres = NS, kAxis = NA, kPlanes = NG;
+    int n_sph, n_x, n_y, n_z, n_gp;
+    int idx_sph[NS > 0 ? NS : 1];
+    int idx_ax[3][NA > 0 ? NA : 1];
+    int idx_gp[NG > 0 ? NG : 1];
+    float sph[NS > 0 ? NS : 1][4];     // cx, cy, cz, r
+    float ax[3][NA > 0 ? NA : 1][2];   // offset, dir
+    float gp[NG > 0 ? NG : 1][4];      // nx, ny, nz, distance
+};
+typedef GroupedSmall<2, 2, 0> GroupedTierA;  // e.g. two spheres in an axis-aligned room
+typedef GroupedSmall<4, 4, 2> GroupedTierB;
+
+struct GroupedLarge {
+    int n_sph, n_x, n_y, n_z, n_gp;
+    const int *idx_sph;  // original object index of each entry
+    const int *idx_ax[3];
+    const int *idx_gp;
+    const float *sph;  // [n_sph][4]
+    const float *ax[3];  // [n][2]
+    const float *gp;     // [n_gp][4]
 };
 
 struct SceneView {

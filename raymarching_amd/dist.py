@@ -1,0 +1,97 @@
+"""Multi-GPU decomposition: one process per GPU, torch.distributed (RCCL) between them.
+
+Frames shard by screen band: rank r renders rows band_rows(H, r, world) and one
+all-gather leaves the whole frame on every rank.  Radiosity shards by receiver
+patch: each rank computes its rows of the form-factor matrix once, then per
+bounce its slice of the next emissive map, and one all-gather per bounce
+exchanges the slices (Jacobi: bounce k reads only bounce k-1, engine.rs:299-325).
+
+Nothing here touches the GPU directly; callers pass tensors on whatever device
+their process group uses (cuda for nccl, cpu for gloo).
+"""
+from typing import Callable, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def band_rows(height: int, rank: int, world: int) -> Tuple[int, int]:
+    """Rows [r0, r1) of rank `rank`: equal bands of ceil(height/world) rows, the last ones clipped."""
+    band = (height + world - 1) // world
+    r0 = min(rank * band, height)
+    return r0, min(r0 + band, height)
+
+
+def patch_range(n_patches: int, rank: int, world: int) -> Tuple[int, int]:
+    """Receiver patches [p0, p1) of rank `rank` (contiguous, equal except the tail)."""
+    per = (n_patches + world - 1) // world
+    p0 = min(rank * per, n_patches)
+    return p0, min(p0 + per, n_patches)
+
+
+def gather_frame(render_band: Callable[[int, int], torch.Tensor], width: int, height: int, group=None) -> torch.Tensor:
+    """Render this rank's band with `render_band(r0, r1) -> uint8 [r1-r0][width][4]` and
+    all-gather the bands into the full [height][width][4] frame on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    r0, r1 = band_rows(height, rank, world)
+    band = render_band(r0, r1)
+    if world == 1:
+        return band
+    band_h = (height + world - 1) // world
+    padded = torch.zeros((band_h, width, 4), dtype=torch.uint8, device=band.device)
+    padded[: r1 - r0] = band
+    full = torch.empty((world * band_h, width, 4), dtype=torch.uint8, device=band.device)
+    dist.all_gather_into_tensor(full.view(-1), padded.view(-1), group=group)
+    return full[:height]
+
+
+def gather_patches(local: torch.Tensor, n_patches: int, group=None) -> torch.Tensor:
+    """All-gather per-patch rows: `local` is this rank's [p1-p0][k] slice; returns [n_patches][k]."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    per = (n_patches + world - 1) // world
+    padded = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    full = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full.view(-1), padded.view(-1), group=group)
+    return full[:n_patches]
+
+
+def compute_lightmaps_sharded(engine, bounces: int = 4, group=None):
+    """Engine::compute_lightmaps (engine.rs:246-326) with receiver patches split over the
+    ranks of `group`.  `engine` is this rank's raymarching_amd.Engine; tensors alias its
+    device buffers, so the gathers write straight into them."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    engine.radiosity_begin()
+    em_ptr, lm_ptr, n = engine.radiosity_buffers()
+    p0, p1 = patch_range(n, rank, world)
+    if bounces > 0:
+        engine.radiosity_form_factors(p0, p1)
+    if world == 1:
+        for _ in range(bounces):
+            engine.radiosity_bounce(p0, p1)
+            engine.radiosity_commit()
+        engine.synchronize()
+        return
+    emissive = _alias_f32(em_ptr, n * 3, engine.device).view(n, 3)
+    lightmaps = _alias_f32(lm_ptr, n * 3, engine.device).view(n, 3)
+    for _ in range(bounces):
+        engine.radiosity_bounce(p0, p1)
+        engine.synchronize()
+        emissive.copy_(gather_patches(emissive[p0:p1].clone(), n, group))
+        engine.radiosity_commit()
+    engine.synchronize()
+    lightmaps.copy_(gather_patches(lightmaps[p0:p1].clone(), n, group))
+    torch.cuda.synchronize()
+
+
+def _alias_f32(ptr: int, count: int, device: int) -> torch.Tensor:
+    """A float32 CUDA tensor over `count` floats of existing device memory at `ptr`."""
+
+    class _Mem:
+        __cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+    return torch.as_tensor(_Mem(), device=torch.device("cuda", device))

@@ -55,7 +55,7 @@ def load(counting=False):
     lib.orc_compute_lightmaps.argtypes = [c_void_p, c_int, _F, _F]
     lib.orc_get_lightmap.argtypes = [c_void_p, c_int, _F]
     lib.orc_set_lightmap.argtypes = [c_void_p, c_int, _F]
-    lib.orc_render.argtypes = [c_void_p, POINTER(c_uint8), c_int, c_int, c_int, c_int, c_int, c_int, _F, c_int, c_int]
+    lib.orc_render.argtypes = [c_void_p, POINTER(c_uint8), c_int, c_int, c_int, c_int, c_int, c_int, c_int, _F, c_int, c_int]
     lib.orc_pose.argtypes = [c_void_p, c_int, c_int, _F, c_int, _F]
     lib.orc_trace_primary.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_int32), POINTER(c_int32), _F]
     lib.orc_fxaa.argtypes = [POINTER(c_uint8), POINTER(c_uint8), c_int, c_int, c_int]
@@ -164,10 +164,11 @@ class OracleEngine:
         v = np.ascontiguousarray(values, dtype=np.float32)
         assert self.lib.orc_set_lightmap(self.handle, obj, v.ctypes.data_as(_F)) == 0
 
-    def render(self, width, height, mouse_x=0, mouse_y=0, rel_move=(0.0, 0.0, 0.0), scroll=0, rows=None, threads=0):
+    def render(self, width, height, mouse_x=0, mouse_y=0, rel_move=(0.0, 0.0, 0.0), scroll=0, rows=None, threads=0, row_step=1):
         row0, row1 = (0, height) if rows is None else rows
-        buf = np.empty((row1 - row0, width, 4), dtype=np.uint8)
-        self.lib.orc_render(self.handle, buf.ctypes.data_as(POINTER(c_uint8)), width, height, row0, row1, mouse_x, mouse_y, _fa(rel_move), scroll, threads)
+        n_rows = (row1 - row0 + row_step - 1) // row_step
+        buf = np.empty((n_rows, width, 4), dtype=np.uint8)
+        self.lib.orc_render(self.handle, buf.ctypes.data_as(POINTER(c_uint8)), width, height, row0, row1, row_step, mouse_x, mouse_y, _fa(rel_move), scroll, threads)
         return buf
 
     def pose(self, mouse_x=0, mouse_y=0, rel_move=(0.0, 0.0, 0.0), scroll=0):
