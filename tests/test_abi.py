@@ -1,0 +1,65 @@
+"""The C ABI library without a GPU: it loads, exports every symbol include/rm.h declares,
+builds scenes on the host, and refuses loudly to create an engine when no device exists."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import gpu_available
+from raymarching_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(lib, name), f"{name} is declared in rm.h but missing from librm_hip.so"
+    # and the Python binding table covers the header one to one
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.rm_version() >= 1
+
+
+def test_scene_construction_and_argument_errors():
+    lib = _lib.load()
+    scene = ctypes.c_void_p(lib.rm_scene_create())
+    mat = _lib.Material(0.25, 1.0, 0.0, 4.0, 0.0, 0.0)
+    white = _lib.f3((1, 1, 1))
+    assert lib.rm_scene_add_sphere(scene, _lib.f3((0, 0, 0)), 1.0, mat, white) == 0
+    assert lib.rm_scene_add_xplane(scene, -3.0, 1.0, mat, white) == 1
+    # YPlane::new takes a texture: refused without one
+    assert lib.rm_scene_add_yplane(scene, -2.0, 1.0, mat, white, 0) < 0
+    assert b"texture" in lib.rm_last_error()
+    px = np.zeros((2, 2, 3), dtype=np.uint8)
+    tex = lib.rm_texture_create_rgb8(scene, px.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), 2, 2, 1.0, 1.0)
+    assert tex == 0
+    assert lib.rm_scene_add_yplane(scene, -2.0, 1.0, mat, white, tex) == 2
+    assert lib.rm_scene_add_zplane(scene, 2.0, -1.0, mat, white) == 3
+    assert lib.rm_scene_add_plane(scene, _lib.f3((0, 1, 0)), 0.0, mat, white) == 4
+    assert lib.rm_texture_create_rgb8(scene, None, 2, 2, 1.0, 1.0) < 0
+    assert lib.rm_scene_add_sphere(scene, None, 1.0, mat, white) < 0
+    assert lib.rm_scene_set_light(scene, _lib.f3((0, 1, 0)), 2.0) == 0
+    assert lib.rm_scene_set_camera(scene, None) != 0
+    # bad engine arguments never reach the device
+    assert not lib.rm_engine_create(scene, 0, 10, 8, 0)
+    assert not lib.rm_engine_create(None, 10, 10, 8, 0)
+    assert lib.rm_engine_render_rows_device(None, None, 0, 0, 0) != 0
+    lib.rm_scene_destroy(scene)
+
+
+@pytest.mark.skipif(gpu_available(), reason="checks the no-GPU error path")
+def test_engine_creation_fails_loudly_without_gpu(scene):
+    from raymarching_amd import Engine
+
+    with pytest.raises(_lib.RMError, match="HIP device|hip"):
+        Engine(scene, 64, 64)

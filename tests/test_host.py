@@ -1,0 +1,57 @@
+"""Host-side logic: asset decode, scene description, band and patch partitions."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from raymarching_amd import dist as rdist
+from raymarching_amd.bmp import load_bmp_rgb8
+from raymarching_amd.scene import (SOFT_GRAY, WHITE, Material, Sphere, XPlane, YPlane, ZPlane, default_scene,
+                                   default_texture_path)
+
+
+def test_floor_texture_decode():
+    rgb, w, h = load_bmp_rgb8(default_texture_path())
+    assert (w, h) == (128, 128) and rgb.shape == (128, 128, 3)
+    assert tuple(rgb[0, 0]) == (233, 197, 143)  # top-left pixel after the bottom-up rows are flipped
+    assert hashlib.sha256(rgb.tobytes()).hexdigest().startswith("3ad07a16")
+
+
+def test_bmp_rejects_other_formats(tmp_path):
+    p = tmp_path / "x.bmp"
+    p.write_bytes(b"PNG" + b"\0" * 64)
+    with pytest.raises(ValueError):
+        load_bmp_rgb8(str(p))
+
+
+def test_default_scene_matches_main_rs():
+    s = default_scene()
+    kinds = [type(o) for o in s.objects]
+    assert kinds == [Sphere, Sphere, YPlane, YPlane, XPlane, XPlane, ZPlane, ZPlane]  # main.rs:157-192
+    assert s.camera_position == (0.0, 0.5, -3.5) and s.light.position == (2.0, -1.0, 1.5) and s.light.intensity == 3.5
+    assert s.objects[0].material == Material(0.05, 0.03, 0.2, 16.0, 1.0, 0.0) and s.objects[0].colour == WHITE
+    assert s.objects[2].y == -2.0 and s.objects[2].dir == 1.0 and s.objects[3].y == 4.0 and s.objects[3].dir == -1.0
+    assert s.objects[6].colour == SOFT_GRAY and s.objects[2].material == Material.basic()
+    assert s.objects[2].texture is s.objects[3].texture and s.objects[2].texture.uscale == 32.0
+
+
+@pytest.mark.parametrize("height,world", [(2160, 8), (2160, 1), (600, 7), (5, 8), (1080, 4)])
+def test_band_rows_partition(height, world):
+    rows = [rdist.band_rows(height, r, world) for r in range(world)]
+    assert rows[0][0] == 0 and rows[-1][1] == height
+    covered = []
+    for r0, r1 in rows:
+        assert 0 <= r0 <= r1 <= height
+        covered.extend(range(r0, r1))
+    assert covered == list(range(height))
+    band = (height + world - 1) // world
+    assert all(r1 - r0 <= band for r0, r1 in rows)
+
+
+@pytest.mark.parametrize("n,world", [(512, 8), (512, 3), (10, 16), (0, 2)])
+def test_patch_range_partition(n, world):
+    covered = []
+    for r in range(world):
+        p0, p1 = rdist.patch_range(n, r, world)
+        covered.extend(range(p0, p1))
+    assert covered == list(range(n))
