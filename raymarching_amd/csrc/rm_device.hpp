@@ -78,7 +78,9 @@ RM_DEV float sdf_eval(int type, float g0, float g1, float g2, float g3, V3 p) {
 // rescaling (below 2^-96), zeros, infinities, negatives and NaNs take that
 // full expansion instead.
 RM_DEV float sqrt_rn(float x) {
-    if (x >= 0x1p-96f && x < __builtin_inff()) {
+    // One scalar branch for the whole wave: the special inputs practically never
+    // occur, and a per-lane branch would cost more mask bookkeeping than it saves.
+    if (__all(x >= 0x1p-96f && x < __builtin_inff())) {
         float s = __builtin_amdgcn_sqrtf(x);
         float sd = __int_as_float(__float_as_int(s) - 1);
         float su = __int_as_float(__float_as_int(s) + 1);
@@ -103,20 +105,20 @@ struct SceneSmallAcc {
     RM_DEV void spheres(F &&f) const {
 #pragma unroll
         for (int i = 0; i < G::kSpheres; i++)
-            if (i < g.n_sph) f(g.idx_sph[i], g.sph[i][0], g.sph[i][1], g.sph[i][2], g.sph[i][3]);
+            if (G::kExact || i < g.n_sph) f(g.idx_sph[i], g.sph[i][0], g.sph[i][1], g.sph[i][2], g.sph[i][3]);
     }
     template <int AXIS, class F>
     RM_DEV void axis(F &&f) const {
         const int n = AXIS == 0 ? g.n_x : (AXIS == 1 ? g.n_y : g.n_z);
 #pragma unroll
         for (int i = 0; i < G::kAxis; i++)
-            if (i < n) f(g.idx_ax[AXIS][i], g.ax[AXIS][i][0], g.ax[AXIS][i][1]);
+            if (G::kExact || i < n) f(g.idx_ax[AXIS][i], g.ax[AXIS][i][0], g.ax[AXIS][i][1]);
     }
     template <class F>
     RM_DEV void planes(F &&f) const {
 #pragma unroll
         for (int i = 0; i < G::kPlanes; i++)
-            if (i < g.n_gp) f(g.idx_gp[i], g.gp[i][0], g.gp[i][1], g.gp[i][2], g.gp[i][3]);
+            if (G::kExact || i < g.n_gp) f(g.idx_gp[i], g.gp[i][0], g.gp[i][1], g.gp[i][2], g.gp[i][3]);
     }
 };
 
@@ -139,9 +141,9 @@ struct SceneLargeAcc {
     }
 };
 
-template <int NS, int NA, int NG>
-RM_DEV SceneSmallAcc<GroupedSmall<NS, NA, NG>> acc_of(const GroupedSmall<NS, NA, NG> &g) {
-    return SceneSmallAcc<GroupedSmall<NS, NA, NG>>{g};
+template <int NS, int NA, int NG, bool EX>
+RM_DEV SceneSmallAcc<GroupedSmall<NS, NA, NG, EX>> acc_of(const GroupedSmall<NS, NA, NG, EX> &g) {
+    return SceneSmallAcc<GroupedSmall<NS, NA, NG, EX>>{g};
 }
 RM_DEV SceneLargeAcc acc_of(const GroupedLarge &g) { return SceneLargeAcc{g}; }
 
@@ -167,8 +169,11 @@ struct LaneIgnore {  // differs between lanes: evaluated, then masked
 // A sphere whose distance provably cannot be below the running minimum skips
 // its square root: with T >= d + r and m >= T*T (both rounded upwards), the
 // correctly rounded sqrt(m) is >= T and sqrt(m) - r rounds to a value >= d.
+//
+// `active` marks the lanes whose result is used: a finished lane must not keep
+// the rest of its wave on the square-root path.
 template <class SC, class IGN>
-RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign) {
+RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, bool active = true) {
     float d = __builtin_inff();
     sc.template axis<0>([&](int oi, float off, float dir) {
         if (!ign.skip(oi)) d = rs_min(d, ign.mask(oi, dir * (p.x - off)));
@@ -188,7 +193,7 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign) {
         float tu = (d + r) * 1.0000005f;
         float q = (tu * tu) * 1.0000005f;
         bool far = (tu > 1e-15f) && (m >= q);
-        if (!far) d = rs_min(d, ign.mask(oi, sqrt_rn(m) - r));
+        if (!far && active) d = rs_min(d, ign.mask(oi, sqrt_rn(m) - r));
     });
     return d;
 }
@@ -221,14 +226,14 @@ RM_DEV int closest_index(const SC &sc, V3 p, float d, const IGN &ign) {
 // ray.rs:15-42 (and ray.rs:58-85: every object type collides, objects.rs:220,343).
 // Returns the hit object or -1; `pos` ends where the reference leaves Ray::position.
 template <class SC, class IGN>
-RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, int &steps, bool &capped) {
+RM_DEV int march_capped(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, int &steps, bool &capped) {
     float travelled = 0.0f;
     float d = 0.0f;
     bool hit = false;
     steps = 0;
     capped = false;
     while (travelled < MAX_MARCH_DISTANCE) {
-        if (cap > 0 && steps >= cap) {
+        if (steps >= cap) {
             capped = true;
             return -1;
         }
@@ -244,6 +249,37 @@ RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, in
     return hit ? closest_index(sc, pos, d, ign) : -1;
 }
 
+// The same loop for the usual case of no iteration cap, written so that the wave
+// runs it with one scalar back-edge: lanes that have finished are frozen by
+// selects instead of being peeled off through execution-mask bookkeeping.
+template <class SC, class IGN>
+RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, int &steps, bool &capped) {
+    if (cap > 0) return march_capped(sc, pos, dir, ign, cap, steps, capped);
+    capped = false;
+    steps = 0;
+    float travelled = 0.0f;
+    float d_hit = 0.0f;
+    bool hit = false;
+    bool active = true;  // travelled = 0 < MAX_MARCH_DISTANCE
+    do {
+        const float d = scene_min(sc, pos, ign, active);
+        const bool near = d < SMALL_DISTANCE;
+        const bool hit_now = active && near;
+        const bool go = active && !near;
+        hit = hit || hit_now;
+        d_hit = hit_now ? d : d_hit;
+        steps += active ? 1 : 0;
+        const float t2 = travelled + d;
+        const V3 p2 = pos + dir * d;
+        travelled = go ? t2 : travelled;
+        pos.x = go ? p2.x : pos.x;
+        pos.y = go ? p2.y : pos.y;
+        pos.z = go ? p2.z : pos.z;
+        active = go && (t2 < MAX_MARCH_DISTANCE);
+    } while (__any(active));
+    return hit ? closest_index(sc, pos, d_hit, ign) : -1;
+}
+
 // `ignore` < 0 means None.  A wave whose lanes all leave out the same object
 // (the usual case: neighbouring pixels hit the same surface) takes the variant
 // that drops it by a scalar branch.
@@ -257,19 +293,26 @@ RM_DEV int march(const SC &sc, V3 &pos, V3 dir, int ignore, int cap, int &steps,
     return march_with(sc, pos, dir, LaneIgnore{ignore}, cap, steps, capped);
 }
 
-// ray.rs:87-118
+// ray.rs:87-118, same loop shape: finished lanes are frozen by selects.
 template <class SC, class IGN>
 RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float light_dist, float k) {
     float travelled = 0.0f;
     float shade = 1.0f;
+    bool active = true;
     for (int it = 0; it < MAX_SHAD_IT; it++) {
-        float d = scene_min(sc, pos, ign);
-        float x = rs_clamp(k * d / travelled, 0.0f, 1.0f);
-        float ss = 3.0f * (x * x) - 2.0f * (x * (x * x));
-        shade = rs_min(shade, ss);
-        travelled += d;
-        pos = pos + dir * d;
-        if (d < SMALL_DISTANCE || travelled > light_dist) break;
+        const float d = scene_min(sc, pos, ign, active);
+        const float x = rs_clamp(k * d / travelled, 0.0f, 1.0f);
+        const float ss = 3.0f * (x * x) - 2.0f * (x * (x * x));
+        const float sh2 = rs_min(shade, ss);
+        const float t2 = travelled + d;
+        const V3 p2 = pos + dir * d;
+        shade = active ? sh2 : shade;
+        travelled = active ? t2 : travelled;
+        pos.x = active ? p2.x : pos.x;
+        pos.y = active ? p2.y : pos.y;
+        pos.z = active ? p2.z : pos.z;
+        active = active && !(d < SMALL_DISTANCE || t2 > light_dist);
+        if (!__any(active)) break;
     }
     return rs_clamp(shade, 0.0f, 1.0f);
 }

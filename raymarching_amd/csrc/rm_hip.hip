@@ -25,9 +25,10 @@ using namespace rm;
 // Kernels
 // ===========================================================================
 
-// A wave is an 8x8 pixel tile, a workgroup 2x2 waves (16x16 pixels).
+// A wave is an 8x8 pixel tile and a workgroup of its own: pixels never cooperate,
+// so a finished wave frees its slot at once instead of waiting for siblings.
 constexpr int TILE = 8;
-constexpr int BLOCK_TILES_X = 2, BLOCK_TILES_Y = 2;
+constexpr int BLOCK_TILES_X = 1, BLOCK_TILES_Y = 1;
 constexpr int BLOCK_W = TILE * BLOCK_TILES_X, BLOCK_H = TILE * BLOCK_TILES_Y;
 constexpr int BLOCK_THREADS = 64 * BLOCK_TILES_X * BLOCK_TILES_Y;
 
@@ -350,7 +351,8 @@ struct rm_engine {
 
     // device-resident scene
     int n = 0, n_lm = 0, n_patches = 0;
-    int tier = 2;  // 0: GroupedTierA, 1: GroupedTierB, 2: GroupedLarge
+    int tier = 2;  // -1: GroupedTierX, 0: GroupedTierA, 1: GroupedTierB, 2: GroupedLarge
+    GroupedTierX tier_x;
     GroupedTierA tier_a;
     GroupedTierB tier_b;
     GroupedLarge large_scene;
@@ -534,7 +536,11 @@ static int engine_upload(rm_engine *e) {
     };
     memset(&e->tier_a, 0, sizeof(e->tier_a));
     memset(&e->tier_b, 0, sizeof(e->tier_b));
-    if (fits(GroupedTierA::kSpheres, GroupedTierA::kAxis, GroupedTierA::kPlanes)) {
+    memset(&e->tier_x, 0, sizeof(e->tier_x));
+    if (gi_sph.size() == 2 && gi_ax[0].size() == 2 && gi_ax[1].size() == 2 && gi_ax[2].size() == 2 && gi_gp.empty()) {
+        e->tier = -1;
+        fill(e->tier_x);
+    } else if (fits(GroupedTierA::kSpheres, GroupedTierA::kAxis, GroupedTierA::kPlanes)) {
         e->tier = 0;
         fill(e->tier_a);
     } else if (fits(GroupedTierB::kSpheres, GroupedTierB::kAxis, GroupedTierB::kPlanes)) {
@@ -634,7 +640,9 @@ static void engine_free(rm_engine *e) {
 // Launches KERNEL<G>(args..., grouped scene) for the engine's scene tier.
 #define RM_LAUNCH(KERNEL, e, grid, block, ...)                                                                \
     do {                                                                                                      \
-        if ((e)->tier == 0)                                                                                   \
+        if ((e)->tier == -1)                                                                                  \
+            hipLaunchKernelGGL((KERNEL<GroupedTierX>), grid, block, 0, (e)->stream, __VA_ARGS__, (e)->tier_x); \
+        else if ((e)->tier == 0)                                                                              \
             hipLaunchKernelGGL((KERNEL<GroupedTierA>), grid, block, 0, (e)->stream, __VA_ARGS__, (e)->tier_a); \
         else if ((e)->tier == 1)                                                                              \
             hipLaunchKernelGGL((KERNEL<GroupedTierB>), grid, block, 0, (e)->stream, __VA_ARGS__, (e)->tier_b); \

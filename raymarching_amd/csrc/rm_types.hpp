@@ -54,9 +54,11 @@ struct TextureRec {
 // planes) is passed by value in the kernel arguments: every field is then
 // addressed by a compile-time constant and lives in scalar registers.  Two tiers
 // are built; larger scenes use the same layout in global memory (GroupedLarge).
-template <int NS, int NA, int NG>
+// EXACT: every slot is in use, so the loops run without count checks.
+template <int NS, int NA, int NG, bool EXACT = false>
 struct GroupedSmall {
     static constexpr int kSpheres = NS, kAxis = NA, kPlanes = NG;
+    static constexpr bool kExact = EXACT;
     int n_sph, n_x, n_y, n_z, n_gp;
     int idx_sph[NS > 0 ? NS : 1];
     int idx_ax[3][NA > 0 ? NA : 1];
@@ -65,7 +67,8 @@ struct GroupedSmall {
     float ax[3][NA > 0 ? NA : 1][2];   // offset, dir
     float gp[NG > 0 ? NG : 1][4];      // nx, ny, nz, distance
 };
-typedef GroupedSmall<2, 2, 0> GroupedTierA;  // e.g. two spheres in an axis-aligned room
+typedef GroupedSmall<2, 2, 0, true> GroupedTierX;  // exactly two spheres in an axis-aligned box of six planes
+typedef GroupedSmall<2, 2, 0> GroupedTierA;
 typedef GroupedSmall<4, 4, 2> GroupedTierB;
 
 struct GroupedLarge {
