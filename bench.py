@@ -7,7 +7,7 @@ as B,G,R,0 bytes into HBM.  With N > 1 the frame is split into N row bands, one
 per rank, and the bands are all-gathered over RCCL so that every rank ends up with
 the whole frame (strong scaling: the work per frame is fixed).
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -29,8 +29,8 @@ PEAK_FP32_NO_FMA_TFLOPS = 78.65  # same issue rate without fused multiply-add
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--fxaa", action="store_true", help="add the FXAA pass to every frame")

@@ -63,6 +63,13 @@ int rm_version(void);
 /* Number of HIP devices visible to the process. */
 int rm_device_count(int *count);
 
+/* Page-locked host memory for frame buffers: rm_engine_render copies into such a
+ * buffer directly at PCIe rate (the reference's destination is the SDL streaming
+ * texture it locks per frame, main.rs:141-145; pageable memory works too, through
+ * an internal staging copy). */
+void *rm_host_alloc(size_t bytes);
+void rm_host_free(void *ptr);
+
 /* ---- scene construction: main.rs:62-71,154-193 ------------------------- */
 
 /* `Vec<Box<dyn EngineObject>>` under construction (main.rs:154-193). */

@@ -24,6 +24,8 @@ SIGNATURES = {
     "rm_last_error": (c_char_p, []),
     "rm_version": (c_int, []),
     "rm_device_count": (c_int, [POINTER(c_int)]),
+    "rm_host_alloc": (c_void_p, [c_size_t]),
+    "rm_host_free": (None, [c_void_p]),
     "rm_scene_create": (c_void_p, []),
     "rm_scene_destroy": (None, [c_void_p]),
     "rm_texture_create_rgb8": (c_int, [c_void_p, POINTER(c_uint8), c_int, c_int, c_float, c_float]),

@@ -239,11 +239,21 @@ __global__ void rad_bounce_kernel(const RadArgs a, int p0, int p1) {
 
 // ---- FXAA (fxaa.txt:1-135, out of place) -------------------------------------
 
+// b / 255.0f for a byte b, correctly rounded, in three operations instead of a
+// full division: one Newton step on b * (1/255) with fused residuals.  Checked
+// against the IEEE quotient for all 256 inputs (tests/test_host.py).
+__device__ __forceinline__ float fx_unorm(unsigned b) {
+    const float c = 1.0f / 255.0f;
+    const float x = (float)b;
+    const float q = x * c;
+    const float r = __builtin_fmaf(-q, 255.0f, x);
+    return __builtin_fmaf(r, c, q);
+}
 __device__ __forceinline__ void fx_load(const unsigned char *src, size_t i, float c[3]) {
     unsigned px = *reinterpret_cast<const unsigned *>(src + i * 4);
-    c[0] = (float)(px & 255u) / 255.0f;
-    c[1] = (float)((px >> 8) & 255u) / 255.0f;
-    c[2] = (float)((px >> 16) & 255u) / 255.0f;
+    c[0] = fx_unorm(px & 255u);
+    c[1] = fx_unorm((px >> 8) & 255u);
+    c[2] = fx_unorm((px >> 16) & 255u);
 }
 __device__ __forceinline__ float fx_luma(const float c[3]) { return (0.299f * c[0] + 0.587f * c[1]) + 0.114f * c[2]; }
 // `as usize` of a rounded offset: negative and NaN become 0
@@ -373,6 +383,7 @@ struct rm_engine {
     float *d_lightmaps = nullptr;  // [n_patches][3]
     unsigned long long *d_stats = nullptr;
     unsigned char *d_frame = nullptr;  // W*H*4, for rm_engine_render
+    unsigned char *h_stage = nullptr;  // pinned W*H*4 staging for callers that pass pageable memory
 
     // radiosity work buffers
     int *d_patch_obj = nullptr;
@@ -630,6 +641,7 @@ static void engine_free(rm_engine *e) {
     (void)hipFree(e->d_stats);
     (void)hipFree(e->d_view);
     (void)hipFree(e->d_frame);
+    if (e->h_stage) (void)hipHostFree(e->h_stage);
     (void)hipFree(e->d_patch_obj);
     (void)hipFree(e->d_pos);
     (void)hipFree(e->d_col);
@@ -686,6 +698,18 @@ extern "C" {
 
 const char *rm_last_error(void) { return g_error.c_str(); }
 int rm_version(void) { return 1; }
+
+void *rm_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        fail(RM_ERR_HIP, "hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+void rm_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
 
 int rm_device_count(int *count) {
     if (!count) return fail(RM_ERR_INVALID, "count is NULL");
@@ -875,9 +899,25 @@ int rm_engine_render(rm_engine *e, uint8_t *bgra, size_t pitch_bytes, int32_t mo
     if (!e->d_frame) HIP_TRY(dev_alloc(&e->d_frame, (size_t)e->W * e->H * 4));
     rc = rm_engine_render_rows_device(e, e->d_frame, (size_t)e->W * 4, 0, e->H);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy2DAsync(bgra, pitch_bytes, e->d_frame, (size_t)e->W * 4, (size_t)e->W * 4, e->H,
-                             hipMemcpyDeviceToHost, e->stream));
+    // Pinned destinations (rm_host_alloc) take the copy directly at PCIe rate;
+    // pageable ones go through a pinned staging frame and one host memcpy per row.
+    hipPointerAttribute_t attr;
+    bool pinned = hipPointerGetAttributes(&attr, bgra) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();  // an unregistered pointer reports an error: not a failure here
+    if (pinned) {
+        HIP_TRY(hipMemcpy2DAsync(bgra, pitch_bytes, e->d_frame, (size_t)e->W * 4, (size_t)e->W * 4, e->H,
+                                 hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        return RM_OK;
+    }
+    if (!e->h_stage) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_stage), (size_t)e->W * e->H * 4, hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(e->h_stage, e->d_frame, (size_t)e->W * e->H * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (pitch_bytes == (size_t)e->W * 4) {
+        memcpy(bgra, e->h_stage, (size_t)e->W * e->H * 4);
+    } else {
+        for (int y = 0; y < e->H; y++) memcpy(bgra + (size_t)y * pitch_bytes, e->h_stage + (size_t)y * e->W * 4, (size_t)e->W * 4);
+    }
     return RM_OK;
 }
 

@@ -55,3 +55,16 @@ def test_patch_range_partition(n, world):
         p0, p1 = rdist.patch_range(n, r, world)
         covered.extend(range(p0, p1))
     assert covered == list(range(n))
+
+
+def test_byte_over_255_in_three_operations():
+    """The FXAA kernel forms b/255 as q = b*c, r = fma(-q, 255, b), q + r*c with c = 1/255 in f32.
+    For every byte this equals the correctly rounded quotient the reference's `as f32 / 255.0` gives."""
+    f32 = np.float32
+    c = f32(1.0) / f32(255.0)
+    for b in range(256):
+        x = f32(b)
+        q = f32(x * c)
+        r = f32(np.float64(x) - np.float64(q) * 255.0)  # exact product, one rounding: a fused multiply-add
+        q2 = f32(np.float64(q) + np.float64(r) * np.float64(c))
+        assert q2 == f32(x / f32(255.0)), b

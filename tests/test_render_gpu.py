@@ -121,3 +121,27 @@ def test_probe_shade_matches_oracle(scene, gpu_engine, oracle_lightmaps):
     ref = np.stack([ora.shade(o, p, d) for o, p, d in zip(objs, pts, dirs)])
     # linear colours: identical up to the last-bit freedom of powf/atan2f
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6)
+
+
+def test_headless_host_harness(tmp_path, scene, oracle_lightmaps):
+    """The C++ host mirror of main.rs (host/main.cpp) renders the default frame through the C ABI."""
+    import os
+    import struct
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "host", "rm_headless")
+    if not os.path.exists(exe):
+        pytest.skip("host/rm_headless is not built")
+    out = tmp_path / "frame.bmp"
+    res = subprocess.run([exe, "--frames", "2", "--out", str(out), "--texture", os.path.join(root, "assets", "textures", "Floor128.bmp")],
+                         capture_output=True, text=True, timeout=100)
+    assert res.returncode == 0, res.stderr
+    assert res.stdout.count("Elapsed:") == 2
+    data = out.read_bytes()
+    w, h = struct.unpack_from("<ii", data, 18)
+    assert (w, -h) == (W, H)
+    got = np.frombuffer(data, dtype=np.uint8, offset=54).reshape(H, W, 4)
+    lm, _ = oracle_lightmaps
+    ref = make_oracle(scene, lm[-1]).render(W, H)
+    assert_frames_match(got, ref, "headless harness")

@@ -1,0 +1,44 @@
+"""Times rm_engine_render (frame copied into pageable host memory) at 4K: the PCIe-inclusive rate."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from raymarching_amd import Engine, default_scene
+
+W, H = 3840, 2160
+eng = Engine(default_scene(), W, H)
+eng.compute_lightmaps(4)
+buf = np.empty((H, W, 4), dtype=np.uint8)
+for _ in range(5):
+    eng.render(buf)
+t = []
+for _ in range(30):
+    t0 = time.perf_counter()
+    eng.render(buf)
+    t.append(time.perf_counter() - t0)
+t.sort()
+med = t[len(t) // 2]
+print(f"rm_engine_render 4K into pageable host memory: median {med*1e3:.3f} ms -> {W*H/med/1e6:.0f} Mrays/s")
+
+import ctypes
+
+from raymarching_amd import _lib
+
+lib = _lib.load()
+ptr = lib.rm_host_alloc(W * H * 4)
+pinned = np.ctypeslib.as_array((ctypes.c_uint8 * (W * H * 4)).from_address(ptr)).reshape(H, W, 4)
+for _ in range(5):
+    eng.render(pinned)
+t = []
+for _ in range(30):
+    t0 = time.perf_counter()
+    eng.render(pinned)
+    t.append(time.perf_counter() - t0)
+t.sort()
+med = t[len(t) // 2]
+print(f"rm_engine_render 4K into rm_host_alloc memory: median {med*1e3:.3f} ms -> {W*H/med/1e6:.0f} Mrays/s")
+assert np.array_equal(pinned, buf)
+lib.rm_host_free(ptr)
