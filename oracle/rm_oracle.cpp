@@ -473,7 +473,13 @@ struct Sphere : EngineObject {
 struct Plane : EngineObject {
     Vec3 normal;
     float distance = 0.0f;
-    explicit Plane(int m) : EngineObject(m) { type = T_PLANE; }
+    // plane_funcs!() gives Plane a lightmap (objects.rs:216), so shading one calls the
+    // unimplemented sample_uv_from_pos and aborts.  Stand-in used here and by the HIP
+    // library alike: treat it as an object without a lightmap (engine.rs:158).
+    explicit Plane(int m) : EngineObject(m) {
+        type = T_PLANE;
+        has_lightmap = false;
+    }
     float sdf(const Vec3 &p) const override { return p.dot(normal) - distance; }  // :261
     bool radiosity_collide() const override { return true; }
 };

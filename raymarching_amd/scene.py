@@ -208,3 +208,42 @@ def build_scene(backend, scene: Scene):
             raise TypeError(f"unknown object type {type(obj).__name__}")
     backend.set_light(scene.light.position, scene.light.intensity)
     backend.set_camera(scene.camera_position)
+
+
+def stress_scene(n_spheres: int = 250, seed: int = 0xC0FFEE, texture_path: Optional[str] = None) -> Scene:
+    """A seed-fixed synthetic scene: the default room (six axis planes, textured floor) filled with
+    `n_spheres` small spheres of mixed materials.  It exercises the large-scene path (geometry in
+    global memory) and deep divergence; it has no counterpart in the reference."""
+    if texture_path is None:
+        texture_path = default_texture_path()
+    rng = np.random.Generator(np.random.PCG64(seed))
+    wood = Texture.new(texture_path, 32.0, 32.0)
+    basic = Material.basic()
+    objects: List[object] = []
+    palette = [SOFT_RED, SOFT_GREEN, SOFT_GRAY, SOFT_YELLOW]
+    placed = []  # (centre, radius): spheres keep a gap, so no surface point lies inside another sphere
+    attempts = 0
+    while len(placed) < n_spheres and attempts < 200000:
+        attempts += 1
+        c = rng.uniform([-2.6, -1.6, -1.0], [2.6, 3.4, 1.8])
+        r = float(rng.uniform(0.05, 0.4))
+        if all(np.linalg.norm(c - pc) > r + pr + 0.02 for pc, pr in placed):
+            placed.append((c, r))
+    for i, (c, r) in enumerate(placed):
+        kind = i % 4
+        if kind == 0:
+            mat = Material(0.05, 0.3, 0.2, 16.0, 0.5, 0.0)  # half mirror
+        elif kind == 1:
+            mat = Material(0.1, 1.0, 0.9, 32.0, 0.25, 0.0)  # glossy
+        else:
+            mat = Material(0.25, 1.0, 0.0, 4.0, 0.0, 0.0)  # matt
+        objects.append(Sphere((float(c[0]), float(c[1]), float(c[2])), r, mat, palette[i % len(palette)]))
+    objects += [
+        YPlane(-2.0, 1.0, basic, SOFT_GRAY, wood),
+        YPlane(4.0, -1.0, basic, SOFT_GRAY, wood),
+        XPlane(-3.0, 1.0, basic, SOFT_RED),
+        XPlane(3.0, -1.0, basic, SOFT_GREEN),
+        ZPlane(2.0, -1.0, basic, SOFT_GRAY),
+        ZPlane(-4.0, 1.0, basic, SOFT_GRAY),
+    ]
+    return Scene(objects=objects, camera_position=(0.0, 0.5, -3.5), light=PointLight((2.0, -1.0, 1.5), 3.5))
