@@ -99,12 +99,20 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the ray-marching kernels need an MI355X", file=sys.stderr)
         sys.exit(2)
+    # Rehearsal switches (not used by the driver): RM_BENCH_BACKEND=gloo RM_BENCH_SAME_DEVICE=1 run the
+    # N-rank code path with every rank on GPU 0, for boxes with a single GPU (RCCL refuses that).
+    backend = os.environ.get("RM_BENCH_BACKEND", "nccl")
+    if os.environ.get("RM_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from raymarching_amd import Engine, default_scene
-    from raymarching_amd.dist import band_rows
+    from raymarching_amd.dist import STRIP_ROWS, band_rows, deinterleave_strips, strip_plan
     from raymarching_amd.flops import frame_flops
 
     W, H = args.width, args.height
@@ -115,11 +123,23 @@ def main():
     eng.compute_lightmaps(4)  # main.rs:73: once, before the frame loop (not timed)
     eng.input(0, 0, (0.0, 0.0, 0.0), 0)  # first-frame pose (main.rs:78-80,122)
 
-    band_h = (H + world - 1) // world
-    r0, r1 = band_rows(H, rank, world)
+    # Sharding: without FXAA rank r renders the 8-row strips r, r+N, r+2N, ... (even load however
+    # the cost is spread over the image); with FXAA it renders one contiguous band plus the few rows
+    # the filter reads around it.  Either way every rank contributes the same number of rows.
+    interleaved = world > 1 and not args.fxaa
+    if interleaved:
+        first_strip, strip_stride, strips_per_rank = strip_plan(H, rank, world)
+        band_h = strips_per_rank * STRIP_ROWS
+        my_rows = sum(min(STRIP_ROWS, H - (first_strip + k * strip_stride) * STRIP_ROWS)
+                      for k in range(strips_per_rank) if (first_strip + k * strip_stride) * STRIP_ROWS < H)
+        r0, r1 = 0, my_rows  # only the row count is used below
+    else:
+        band_h = (H + world - 1) // world
+        r0, r1 = band_rows(H, rank, world)
     # double-buffered so that the gather of frame f overlaps the render of frame f+1
     bands = [torch.zeros((band_h, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
     frames = [torch.zeros((world * band_h, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    final = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)] if interleaved else None
     fx_src = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") if args.fxaa else None
 
     kernel_events = []
@@ -137,12 +157,40 @@ def main():
                 ev1.record(stream)
             # the band buffer stands in for rows r0.. of a frame-shaped destination
             eng.fxaa_device(fx_src.data_ptr(), buf.data_ptr() - r0 * W * 4, r0, r1)
+        elif interleaved:
+            eng.render_strips_device(buf.data_ptr(), first_strip, strip_stride, strips_per_rank)
+            if timed:
+                ev1.record(stream)
         else:
             eng.render_rows_device(buf.data_ptr(), r0, r1)
             if timed:
                 ev1.record(stream)
         if timed:
             kernel_events.append((ev0, ev1))
+
+    class _HostStagedGather:
+        """gloo rehearsal only: all-gather through host memory, same interface as an async work handle."""
+
+        def __init__(self, out, inp):
+            cpu_in = inp.cpu()
+            cpu_out = torch.empty(out.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(cpu_out, cpu_in)
+            out.copy_(cpu_out)
+
+        def wait(self):
+            pass
+
+    def start_gather(out, inp):
+        if backend == "nccl":
+            return dist.all_gather_into_tensor(out, inp, async_op=True)
+        return _HostStagedGather(out, inp)
+
+    def finish(pending):
+        """Frame f is complete on this rank once its gather has landed (and, for strips, been put in row order)."""
+        work, b = pending
+        work.wait()
+        if interleaved:
+            final[b].copy_(deinterleave_strips(frames[b], world, strips_per_rank, W, H))
 
     def run(steps, timed):
         pending = None
@@ -151,13 +199,13 @@ def main():
             render_band(bands[b], timed)
             if world > 1:
                 if pending is not None:
-                    pending.wait()
-                pending = dist.all_gather_into_tensor(frames[b].view(-1), bands[b].view(-1), async_op=True)
+                    finish(pending)
+                pending = (start_gather(frames[b].view(-1), bands[b].view(-1)), b)
                 if args.no_overlap:
-                    pending.wait()
+                    finish(pending)
                     pending = None
         if pending is not None:
-            pending.wait()
+            finish(pending)
 
     def fence():
         torch.cuda.synchronize()
@@ -172,7 +220,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -220,6 +268,7 @@ def main():
                 "width": W,
                 "height": H,
                 "bands": world,
+                "sharding": "interleaved 8-row strips" if interleaved else "contiguous row bands",
                 "fxaa": bool(args.fxaa),
                 "map_size": 8,
                 "overlap_gather": world > 1 and not args.no_overlap,
@@ -233,7 +282,7 @@ def main():
             result["cpu_baseline"] = base
             if not args.fxaa:
                 # the same frame from the GPU: a parity check at the benchmarked size
-                full = frames[(args.steps - 1) & 1] if world > 1 else None
+                full = (final if interleaved else frames)[(args.steps - 1) & 1] if world > 1 else None
                 if full is None:
                     full = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
                     eng.render_rows_device(full.data_ptr(), 0, H)

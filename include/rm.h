@@ -160,6 +160,16 @@ int rm_engine_render(rm_engine *engine, uint8_t *bgra, size_t pitch_bytes, int32
  * the engine's stream. */
 int rm_engine_render_rows_device(rm_engine *engine, void *d_bgra, size_t pitch_bytes, int row_begin, int row_end);
 
+/* The same passes for every `strip_stride`-th strip of RM_STRIP_ROWS image rows,
+ * starting with strip `first_strip` (strip s covers rows [8s, 8s+8)), `n_strips` of
+ * them, written compactly: strip k of the selection lands at rows [8k, 8k+8) of
+ * `d_bgra`.  Strips beyond the frame are skipped.  This is how a frame is split
+ * over GPUs with even load: rank r of n renders strips r, r+n, r+2n, ...  No
+ * counterpart in the reference (one process, rayon rows, engine.rs:93). */
+#define RM_STRIP_ROWS 8
+int rm_engine_render_strips_device(rm_engine *engine, void *d_bgra, size_t pitch_bytes, int first_strip,
+                                   int strip_stride, int n_strips);
+
 /* FXAA (fxaa.txt:1-135, a commented-out block nothing in the reference calls),
  * defined here out of place: every tap is read from `d_src`.  Both buffers hold
  * whole frames of width*4-byte rows; rows [row_begin,row_end) of `d_dst` are

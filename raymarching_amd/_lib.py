@@ -52,6 +52,7 @@ SIGNATURES = {
     "rm_engine_set_camera": (c_int, [c_void_p, _F3]),
     "rm_engine_render": (c_int, [c_void_p, POINTER(c_uint8), c_size_t, c_int32, c_int32, _F3, c_int32]),
     "rm_engine_render_rows_device": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int]),
+    "rm_engine_render_strips_device": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int]),
     "rm_engine_fxaa_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "rm_engine_trace_primary": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_float)]),
     "rm_engine_probe_shade": (c_int, [c_void_p, c_int, POINTER(c_int32), POINTER(c_float), POINTER(c_float), POINTER(c_float)]),
@@ -74,6 +75,13 @@ def load():
             f"{LIB_PATH} is missing: build it with `make -C raymarching_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
         )
+    # PyTorch wheels bundle a HIP runtime under the same soname as the system one, and a process can
+    # only work with one: whichever is loaded first serves both.  Loading torch's first keeps
+    # torch.cuda usable next to this library (the reverse order leaves torch without GPUs).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -28,6 +28,7 @@ using namespace rm;
 // A wave is an 8x8 pixel tile and a workgroup of its own: pixels never cooperate,
 // so a finished wave frees its slot at once instead of waiting for siblings.
 constexpr int TILE = 8;
+static_assert(TILE == RM_STRIP_ROWS, "a strip is one row of wave tiles");
 constexpr int BLOCK_THREADS = 64;
 
 struct RenderArgs {
@@ -35,6 +36,7 @@ struct RenderArgs {
     Pose pose;
     int row_begin, row_end;
     int blocks_x, blocks_y;
+    int tile_row_stride;  // 1 = contiguous rows; n = every n-th 8-row strip, written compactly
     unsigned char *out;  // first byte of row `row_begin`
     size_t pitch;
 };
@@ -43,33 +45,34 @@ struct RenderArgs {
 // floor and things standing on it the lower rows cost most, and starting them
 // first leaves the cheap tiles to fill the tail of the launch (measured: 10 %
 // off the 4K frame of the default scene).  Any order renders the same pixels.
-__device__ __forceinline__ void tile_pixel(int blocks_x, int blocks_y, int row_begin, int &x, int &y_inv) {
+__device__ __forceinline__ void tile_pixel(const RenderArgs &a, int &x, int &y_inv, int &out_row) {
     const int lane = threadIdx.x & 63;
-    const int by = blocks_y - 1 - blockIdx.x / blocks_x;
-    const int bx = blockIdx.x % blocks_x;
+    const int by = a.blocks_y - 1 - blockIdx.x / a.blocks_x;
+    const int bx = blockIdx.x % a.blocks_x;
     x = bx * TILE + (lane & 7);
-    y_inv = row_begin + by * TILE + (lane >> 3);
+    out_row = by * TILE + (lane >> 3);
+    y_inv = a.row_begin + by * a.tile_row_stride * TILE + (lane >> 3);
 }
 
 // engine.rs:77-126 fused: direction, cast_sight_ray, tone map, pack.
 template <class G>
 __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderArgs a, const G g) {
-    int x, y_inv;
-    tile_pixel(a.blocks_x, a.blocks_y, a.row_begin, x, y_inv);
+    int x, y_inv, out_row;
+    tile_pixel(a, x, y_inv, out_row);
     if (x >= a.pose.W || y_inv >= a.row_end) return;
     V3 dir = pixel_direction(a.pose, x, y_inv);
     V3 cam = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
     V3 colour = cast_sight_ray(acc_of(g), *a.sv, cam, dir);
     unsigned px = pack_pixel(colour, a.pose.exposure);
-    *reinterpret_cast<unsigned *>(a.out + (size_t)(y_inv - a.row_begin) * a.pitch + (size_t)x * 4) = px;
+    *reinterpret_cast<unsigned *>(a.out + (size_t)out_row * a.pitch + (size_t)x * 4) = px;
 }
 
 // Primary march only: hit object, iteration count, final position.
 template <class G>
 __global__ __launch_bounds__(BLOCK_THREADS) void trace_kernel(const RenderArgs a, int *hit, int *steps_out,
                                                               float *pos_out, const G g) {
-    int x, y_inv;
-    tile_pixel(a.blocks_x, a.blocks_y, a.row_begin, x, y_inv);
+    int x, y_inv, out_row;
+    tile_pixel(a, x, y_inv, out_row);
     if (x >= a.pose.W || y_inv >= a.row_end) return;
     V3 dir = pixel_direction(a.pose, x, y_inv);
     V3 pos = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
@@ -684,6 +687,7 @@ static RenderArgs make_render_args(rm_engine *e, void *d_out, size_t pitch, int 
     a.row_end = row_end;
     a.blocks_x = (e->W + TILE - 1) / TILE;
     a.blocks_y = (row_end - row_begin + TILE - 1) / TILE;
+    a.tile_row_stride = 1;
     a.out = static_cast<unsigned char *>(d_out);
     a.pitch = pitch;
     grid = dim3((unsigned)(a.blocks_x * a.blocks_y), 1, 1);
@@ -883,6 +887,24 @@ int rm_engine_render_rows_device(rm_engine *e, void *d_bgra, size_t pitch_bytes,
     if (int rc_ = sync_view(e)) return rc_;
     dim3 grid;
     RenderArgs a = make_render_args(e, d_bgra, pitch_bytes, row_begin, row_end, grid);
+    RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);
+    HIP_TRY(hipGetLastError());
+    return RM_OK;
+}
+
+int rm_engine_render_strips_device(rm_engine *e, void *d_bgra, size_t pitch_bytes, int first_strip, int strip_stride,
+                                   int n_strips) {
+    if (!e || !d_bgra) return fail(RM_ERR_INVALID, "NULL argument");
+    if (first_strip < 0 || strip_stride < 1 || n_strips < 0) return fail(RM_ERR_INVALID, "bad strip selection");
+    if (pitch_bytes < (size_t)e->W * 4 || (pitch_bytes & 3)) return fail(RM_ERR_INVALID, "pitch must be >= width*4 and a multiple of 4");
+    if (n_strips == 0 || first_strip * RM_STRIP_ROWS >= e->H) return RM_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
+    dim3 grid;
+    RenderArgs a = make_render_args(e, d_bgra, pitch_bytes, first_strip * RM_STRIP_ROWS, e->H, grid);
+    a.blocks_y = n_strips;
+    a.tile_row_stride = strip_stride;
+    grid = dim3((unsigned)(a.blocks_x * a.blocks_y), 1, 1);
     RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);
     HIP_TRY(hipGetLastError());
     return RM_OK;

@@ -29,6 +29,41 @@ def patch_range(n_patches: int, rank: int, world: int) -> Tuple[int, int]:
     return p0, min(p0 + per, n_patches)
 
 
+STRIP_ROWS = 8  # RM_STRIP_ROWS: one row of 8x8 wave tiles
+
+
+def strip_plan(height: int, rank: int, world: int) -> Tuple[int, int, int]:
+    """(first_strip, strip_stride, strips_per_rank) of rank `rank`: it renders strips
+    rank, rank+world, ... of 8 rows each.  Every rank gets the same count (strips past the
+    frame are skipped by the renderer), so one all-gather of equal parts moves them."""
+    n_strips = (height + STRIP_ROWS - 1) // STRIP_ROWS
+    per_rank = (n_strips + world - 1) // world
+    return rank, world, per_rank
+
+
+def deinterleave_strips(gathered: torch.Tensor, world: int, per_rank: int, width: int, height: int) -> torch.Tensor:
+    """[world][per_rank*8][width][4] as all-gathered -> the frame [height][width][4]:
+    strip k of rank r is frame strip k*world + r."""
+    g = gathered.view(world, per_rank, STRIP_ROWS, width, 4)
+    frame = g.permute(1, 0, 2, 3, 4).reshape(per_rank * world * STRIP_ROWS, width, 4)
+    return frame[:height]
+
+
+def gather_frame_interleaved(render_strips: Callable[[int, int, int], torch.Tensor], width: int, height: int,
+                             group=None) -> torch.Tensor:
+    """Load-balanced variant of gather_frame: `render_strips(first, stride, n)` returns the
+    compact uint8 [n*8][width][4] image of this rank's strips; the result is the whole frame."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    first, stride, per_rank = strip_plan(height, rank, world)
+    mine = render_strips(first, stride, per_rank)
+    if world == 1:
+        return mine[:height]
+    gathered = torch.empty((world,) + tuple(mine.shape), dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1), group=group)
+    return deinterleave_strips(gathered, world, per_rank, width, height)
+
+
 def gather_frame(render_band: Callable[[int, int], torch.Tensor], width: int, height: int, group=None) -> torch.Tensor:
     """Render this rank's band with `render_band(r0, r1) -> uint8 [r1-r0][width][4]` and
     all-gather the bands into the full [height][width][4] frame on every rank."""

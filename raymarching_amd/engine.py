@@ -161,6 +161,14 @@ class Engine:
         pitch = self.width * 4 if pitch is None else pitch
         _lib.check(self.lib.rm_engine_render_rows_device(self.handle, c_void_p(d_ptr), pitch, row_begin, row_end), "rm_engine_render_rows_device")
 
+    def render_strips_device(self, d_ptr: int, first_strip: int, strip_stride: int, n_strips: int, pitch=None):
+        """Strips first, first+stride, ... (8 rows each) at the current pose, written compactly at d_ptr (async)."""
+        pitch = self.width * 4 if pitch is None else pitch
+        _lib.check(
+            self.lib.rm_engine_render_strips_device(self.handle, c_void_p(d_ptr), pitch, first_strip, strip_stride, n_strips),
+            "rm_engine_render_strips_device",
+        )
+
     def fxaa_device(self, d_src: int, d_dst: int, row_begin: int, row_end: int):
         _lib.check(self.lib.rm_engine_fxaa_device(self.handle, c_void_p(d_src), c_void_p(d_dst), row_begin, row_end), "rm_engine_fxaa_device")
 

@@ -99,6 +99,30 @@ def test_rows_equal_full_frame(scene, gpu_engine):
         assert torch.equal(band, full[r0:r1])
 
 
+def test_strips_equal_full_frame(scene, gpu_engine):
+    """Every n-th 8-row strip rendered compactly equals those rows of the full frame, and the
+    strips of all ranks reassemble to it (interleaved sharding over GPUs)."""
+    import torch
+
+    from raymarching_amd import dist as rdist
+
+    gpu_engine.camera_position = scene.camera_position
+    gpu_engine.input(0, 0, (0, 0, 0), 0)
+    full = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+    gpu_engine.render_rows_device(full.data_ptr(), 0, H)
+    for world in (1, 3, 8):
+        parts = []
+        for rank in range(world):
+            first, stride, per = rdist.strip_plan(H, rank, world)
+            buf = torch.zeros((per * 8, W, 4), dtype=torch.uint8, device="cuda")
+            gpu_engine.render_strips_device(buf.data_ptr(), first, stride, per)
+            parts.append(buf)
+        gpu_engine.synchronize()
+        _, _, per = rdist.strip_plan(H, 0, world)
+        frame = rdist.deinterleave_strips(torch.stack(parts), world, per, W, H)
+        assert torch.equal(frame, full), world
+
+
 def test_probe_shade_matches_oracle(scene, gpu_engine, oracle_lightmaps):
     """Engine::shade_object at scattered surface points, including the reflective spheres."""
     lm, _ = oracle_lightmaps
