@@ -37,6 +37,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the CPU baseline leg")
     ap.add_argument("--no-overlap", action="store_true", help="wait for each frame's all-gather before the next render")
+    ap.add_argument("--workload", choices=["render", "radiosity"], default="render",
+                    help="render: the headline frame benchmark; radiosity: Engine::compute_lightmaps, patch-sharded")
+    ap.add_argument("--map-size", type=int, default=8, help="lightmap edge for --workload radiosity (8 in the reference)")
     return ap.parse_args()
 
 
@@ -83,6 +86,64 @@ def cpu_baseline(scene, lightmaps, width, height, budget_s):
     }, frame
 
 
+def radiosity_workload(args, world, rank, local_rank, backend):
+    """One step = Engine::compute_lightmaps (engine.rs:246-326): clouds, direct lighting, the
+    form-factor matrix of all patch pairs, 4 bounces; receiver patches sharded over the ranks with
+    one all-gather per bounce."""
+    import torch
+    import torch.distributed as dist
+
+    from raymarching_amd import Engine, default_scene
+    from raymarching_amd.dist import compute_lightmaps_sharded
+
+    M = args.map_size
+    eng = Engine(default_scene(), 64, 64, map_size=M, device=local_rank)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    steps, warmup = min(args.steps, 20), min(args.warmup, 3)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        compute_lightmaps_sharded(eng, 4)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        compute_lightmaps_sharded(eng, 4)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        n = 8 * M * M
+        pairs = n * (n - M * M)
+        print(json.dumps({
+            "metric": "radiosity occlusion marches per second (Engine::compute_lightmaps, 4 bounces)",
+            "value": pairs / (elapsed / steps) / 1e6,
+            "unit": "Mmarches/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic: the reference's default scene",
+            "config": {"workload": f"compute_lightmaps, default scene, MAP_SIZE={M}, 4 bounces", "map_size": M,
+                       "patches": n, "patch_pairs": pairs, "sharding": "receiver patches, all-gather per bounce"},
+        }), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -114,6 +175,10 @@ def main():
     from raymarching_amd import Engine, default_scene
     from raymarching_amd.dist import STRIP_ROWS, band_rows, deinterleave_strips, strip_plan
     from raymarching_amd.flops import frame_flops
+
+    if args.workload == "radiosity":
+        radiosity_workload(args, world, rank, local_rank, backend)
+        return
 
     W, H = args.width, args.height
     scene = default_scene()

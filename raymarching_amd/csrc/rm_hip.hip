@@ -217,19 +217,41 @@ __global__ void rad_form_kernel(const RadArgs a, int p0, int p1, const G grp) {
 }
 
 // radiosity.rs:107-156 + 184-192 for one receiver: the ordered sum over sources.
-__global__ void rad_bounce_kernel(const RadArgs a, int p0, int p1) {
-    int i = p0 + blockIdx.x * blockDim.x + threadIdx.x;
+// The additions must run in source order (f32 addition does not associate), but
+// the loads need not wait for them: each thread fetches a batch of form factors
+// before it folds them in, which keeps enough loads in flight to stream FT.
+__global__ __launch_bounds__(64) void rad_bounce_kernel(const RadArgs a, int p0, int p1) {
+    const int i = p0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p1) return;
     const int NP = a.n_patches;
-    V3 incident = v3(0.0f, 0.0f, 0.0f);
-    for (int j = 0; j < NP; j++) {
-        float f = a.ft[(size_t)j * NP + i];
-        if (f != -1.0f) {
-            V3 e = v3(a.emissive[3 * j], a.emissive[3 * j + 1], a.emissive[3 * j + 2]);
-            incident = incident + e * f;
+    const float *__restrict__ ft = a.ft + i;
+    const float *__restrict__ em = a.emissive;
+    float ix = 0.0f, iy = 0.0f, iz = 0.0f;
+    constexpr int U = 16;
+    int j = 0;
+    for (; j + U <= NP; j += U) {
+        float f[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) f[u] = ft[(size_t)(j + u) * NP];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float ex = em[3 * (j + u)], ey = em[3 * (j + u) + 1], ez = em[3 * (j + u) + 2];
+            if (f[u] != -1.0f) {
+                ix = ix + ex * f[u];
+                iy = iy + ey * f[u];
+                iz = iz + ez * f[u];
+            }
         }
     }
-    incident = incident / 3.14159265358979323846f;
+    for (; j < NP; j++) {
+        const float f = ft[(size_t)j * NP];
+        if (f != -1.0f) {
+            ix = ix + em[3 * j] * f;
+            iy = iy + em[3 * j + 1] * f;
+            iz = iz + em[3 * j + 2] * f;
+        }
+    }
+    V3 incident = v3(ix, iy, iz) / 3.14159265358979323846f;
     V3 col = v3(a.col[3 * i], a.col[3 * i + 1], a.col[3 * i + 2]);
     a.lightmaps[3 * i] = a.lightmaps[3 * i] + incident.x;
     a.lightmaps[3 * i + 1] = a.lightmaps[3 * i + 1] + incident.y;

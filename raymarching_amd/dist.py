@@ -81,6 +81,16 @@ def gather_frame(render_band: Callable[[int, int], torch.Tensor], width: int, he
     return full[:height]
 
 
+def _all_gather_flat(out: torch.Tensor, inp: torch.Tensor, group=None):
+    """all_gather_into_tensor; with the gloo backend (CPU rehearsals) device tensors go through host memory."""
+    if out.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(out.numel(), dtype=out.dtype)
+        dist.all_gather_into_tensor(host, inp.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def gather_patches(local: torch.Tensor, n_patches: int, group=None) -> torch.Tensor:
     """All-gather per-patch rows: `local` is this rank's [p1-p0][k] slice; returns [n_patches][k]."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -90,7 +100,7 @@ def gather_patches(local: torch.Tensor, n_patches: int, group=None) -> torch.Ten
     padded = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
     full = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(full.view(-1), padded.view(-1), group=group)
+    _all_gather_flat(full.view(-1), padded.view(-1), group)
     return full[:n_patches]
 
 
@@ -121,6 +131,7 @@ def compute_lightmaps_sharded(engine, bounces: int = 4, group=None):
     engine.synchronize()
     lightmaps.copy_(gather_patches(lightmaps[p0:p1].clone(), n, group))
     torch.cuda.synchronize()
+    engine.synchronize()
 
 
 def _alias_f32(ptr: int, count: int, device: int) -> torch.Tensor:

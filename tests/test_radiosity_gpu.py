@@ -71,3 +71,48 @@ def test_sharded_bounces_equal_whole(scene):
         got = np.stack([e.get_lightmap(i) for i in range(e.n_objects)])
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
         e.close()
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raymarching_amd import Engine, default_scene
+    from raymarching_amd import dist as rdist
+
+    torch.cuda.set_device(0)
+    eng = Engine(default_scene(), 64, 64, device=0)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    rdist.compute_lightmaps_sharded(eng, 4)
+    got = np.stack([eng.get_lightmap(i) for i in range(eng.n_objects)])
+    np.save(os.path.join(out_dir, f"lm_{rank}.npy"), got)
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_patch_sharded_precompute_two_processes(tmp_path, oracle_lightmaps):
+    """compute_lightmaps_sharded with two ranks (both on GPU 0, exchange over gloo): every rank ends
+    up with the oracle's lightmaps, bit for bit."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ref = oracle_lightmaps[0][4]
+    for r in range(2):
+        got = np.load(str(tmp_path / f"lm_{r}.npy"))
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
