@@ -52,6 +52,17 @@ def load_counters(width, height):
         return None
 
 
+def measured_traffic(width, height):
+    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes (4K only)."""
+    if (width, height) != (3840, 2160):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_traffic.json")) as f:
+            return int(json.load(f)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(scene, lightmaps, width, height, budget_s):
     """Times the CPU oracle (test infrastructure) on whole frames of the same workload
     until about `budget_s` seconds of CPU work have been spent (at least 3 frames)."""
@@ -309,7 +320,8 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS,
                 "frac_of_no_fma_peak": achieved / PEAK_FP32_NO_FMA_TFLOPS,
-                "traffic": None,
+                "traffic": int(measured_traffic(W, H) * band_share) if measured_traffic(W, H) else None,
+                "traffic_source": "rocprofv3 PMC passes committed under profiles/ (not collected live)",
                 "kernel": "render_kernel",
                 "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": int(flops * band_share),

@@ -14,6 +14,13 @@ namespace rm {
 
 #define RM_DEV __device__ __forceinline__
 
+// Diagnostic builds (-DRM_ABL=bits) switch parts of the pixel path off to time the rest:
+// 1 soft shadow, 2 reflections, 4 lightmap sampling, 8 everything after the primary march.
+// The shipped library is built with 0.
+#ifndef RM_ABL
+#define RM_ABL 0
+#endif
+
 struct V3 {
     float x, y, z;
 };
@@ -301,9 +308,17 @@ RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float lig
     bool active = true;
     for (int it = 0; it < MAX_SHAD_IT; it++) {
         const float d = scene_min(sc, pos, ign, active);
-        const float x = rs_clamp(k * d / travelled, 0.0f, 1.0f);
-        const float ss = 3.0f * (x * x) - 2.0f * (x * (x * x));
-        const float sh2 = rs_min(shade, ss);
+        // shade = min(shade, smoothstep(clamp(k*d / travelled, 0, 1))).  With a = k*d >= travelled
+        // >= 0 the correctly rounded quotient is >= 1 (or +inf, or NaN for 0/0): the clamp gives 1
+        // (or keeps the NaN), smoothstep(1) = 1, and min(shade, 1 or NaN) leaves shade (<= 1) as it
+        // is.  Lanes in that case skip the division and the polynomial.
+        const float a = k * d;
+        float sh2 = shade;
+        if (!(a >= travelled && travelled >= 0.0f) && active) {
+            const float x = rs_clamp(a / travelled, 0.0f, 1.0f);
+            const float ss = 3.0f * (x * x) - 2.0f * (x * (x * x));
+            sh2 = rs_min(shade, ss);
+        }
         const float t2 = travelled + d;
         const V3 p2 = pos + dir * d;
         shade = active ? sh2 : shade;
@@ -467,7 +482,10 @@ RM_DEV V3 sample_lightmap(const SceneView &sv, const ShadeRec &sr, const Geom &g
     float x1 = (float)u0, x2 = (float)u1, y1 = (float)v0, y2 = (float)v1;
     V3 acc = (((s00 * (x2 - u)) * (y2 - v)) + ((s10 * (u - x1)) * (y2 - v))) + ((s01 * (x2 - u)) * (v - y1));
     acc = acc + ((s11 * (u - x1)) * (v - y1));
-    return acc / ((x2 - x1) * (y2 - y1));
+    // the cell is one luxel wide and high, so the divisor is exactly 1 (x / 1 = x); other values can
+    // only come from indices the reference would have aborted on
+    const float denom = (x2 - x1) * (y2 - y1);
+    return denom == 1.0f ? acc : acc / denom;
 }
 
 // colour.rs:74-98
@@ -504,7 +522,7 @@ RM_DEV ShadeResult shade_local(const SC &sc, const SceneView &sv, int idx, V3 po
     V3 n = calculate_normal(sr.type, g, pos);
 
     V3 ambient;
-    if (sr.lm_slot < 0)
+    if ((RM_ABL & 4) || sr.lm_slot < 0)
         ambient = oc * sr.ambient;  // engine.rs:158
     else
         ambient = sample_lightmap(sv, sr, g, pos);  // engine.rs:159
@@ -518,7 +536,7 @@ RM_DEV ShadeResult shade_local(const SC &sc, const SceneView &sv, int idx, V3 po
 
     float diffuse, specular;
     phong_ds(n, to_light, dist, sv.intensity, sr, dir, diffuse, specular);
-    float shade = smooth_shadow_march(sc, pos, to_light, idx, dist, SHADOW_K);
+    float shade = (RM_ABL & 1) ? 1.0f : smooth_shadow_march(sc, pos, to_light, idx, dist, SHADOW_K);
 
     out.final_colour = ambient + oc * (shade * (diffuse + specular));
     out.object_colour = oc;
@@ -543,8 +561,12 @@ RM_DEV V3 cast_sight_ray(const SC &sc, const SceneView &sv, V3 pos, V3 dir) {
             colour = v3(sv.sky[0], sv.sky[1], sv.sky[2]);
             break;
         }
+        if (RM_ABL & 8) {
+            colour = v3(pos.x * 0.1f + 0.5f, pos.y * 0.1f + 0.5f, (float)idx * 0.1f);
+            break;
+        }
         ShadeResult r = shade_local(sc, sv, idx, pos, dir);
-        if (r.reflectivity > 1e-3f) {
+        if (!(RM_ABL & 2) && r.reflectivity > 1e-3f) {
             if (depth >= MAX_DEPTH) {
                 atomicAdd(&sv.stats[0], 1ULL);
                 colour = r.final_colour;
