@@ -290,7 +290,7 @@ struct Lightmap {
     const Colour &at(uint64_t u, uint64_t v) const { return s[(size_t)(u * m + v)]; }
 };
 
-enum ObjType { T_SPHERE = 0, T_XPLANE = 1, T_YPLANE = 2, T_ZPLANE = 3, T_PLANE = 4 };
+enum ObjType { T_SPHERE = 0, T_XPLANE = 1, T_YPLANE = 2, T_ZPLANE = 3, T_PLANE = 4, T_BOX = 5 };
 
 // colour.rs:47-71
 static Colour bilinear_interpolation(float x, float y, std::array<std::tuple<float, float, Colour>, 4> &points) {
@@ -484,6 +484,33 @@ struct Plane : EngineObject {
     bool radiosity_collide() const override { return true; }
 };
 
+// EXTENSION (not live code in the reference): the box distance of the commented-out block
+// objects.rs:370-380, with the centre and the half extents as parameters (the text has the
+// half extents fixed at 0.7).  Evaluation order as written there.  Like Plane it has no
+// lightmap parameterisation, so it is shaded with the no-lightmap ambient of engine.rs:158.
+struct Box : EngineObject {
+    Vec3 position, half;
+    explicit Box(int m) : EngineObject(m) {
+        type = T_BOX;
+        has_lightmap = false;
+    }
+    float sdf(const Vec3 &pos) const override {
+        Vec3 p = pos - position;
+        Vec3 abs_p(std::fabs(p.x()), std::fabs(p.y()), std::fabs(p.z()));
+        Vec3 q = abs_p - half;
+        Vec3 r(rs_max(q.x(), 0.0f), rs_max(q.y(), 0.0f), rs_max(q.z(), 0.0f));
+        return r.mag() + rs_min(rs_max(q.x(), rs_max(q.y(), q.z())), 0.0f);
+    }
+    bool radiosity_collide() const override { return true; }
+};
+
+// EXTENSION: polynomial smooth minimum used for "smooth unions" (the reference's union is the
+// hard minimum of ray.rs:23-33).  k = 0 is the hard minimum.
+static inline float smooth_min(float a, float b, float k) {
+    float h = rs_max(k - std::fabs(a - b), 0.0f) / k;
+    return rs_min(a, b) - h * h * k * (1.0f / 4.0f);
+}
+
 // objects.rs:177-184, 293-311
 struct XPlane : EngineObject {
     float x = 0.0f, dir = 1.0f;
@@ -570,6 +597,7 @@ static inline void count_sdf(int type, bool shadow) {
 struct Ray {
     Vec3 position, direction;
     uint64_t last_steps = 0;
+    float smooth_k = 0.0f;  // EXTENSION: > 0 blends the object distances with smooth_min, in index order
 
     // ray.rs:15-42 and ray.rs:58-85 (radiosity=true also skips non-colliders)
     uint64_t march(const Objects &objects, uint64_t ignore_index, bool radiosity = false) {
@@ -580,13 +608,22 @@ struct Ray {
             steps++;
             CNT(march_steps, 1);
             float distance = std::numeric_limits<float>::infinity();
+            float raw_best = std::numeric_limits<float>::infinity();
             uint64_t closest_object = NONE;
             for (uint64_t i = 0; i < objects.size(); i++) {
                 if (ignore_index == i) continue;
                 if (radiosity && !objects[i]->radiosity_collide()) continue;
                 count_sdf(objects[i]->type, false);
                 float obj_distance = objects[i]->sdf(position);
-                if (obj_distance < distance) {
+                if (smooth_k > 0.0f) {
+                    // EXTENSION: the step length is the blended distance; the hit object is still
+                    // the one with the smallest own distance (lowest index on ties)
+                    if (obj_distance < raw_best) {
+                        raw_best = obj_distance;
+                        closest_object = i;
+                    }
+                    distance = smooth_min(distance, obj_distance, smooth_k);
+                } else if (obj_distance < distance) {
                     distance = obj_distance;
                     closest_object = i;
                 }
@@ -628,7 +665,10 @@ struct Ray {
                 if (ignore_obj_index == i) continue;
                 count_sdf(objects[i]->type, true);
                 float obj_distance = objects[i]->sdf(position);
-                if (obj_distance < distance) distance = obj_distance;
+                if (smooth_k > 0.0f)
+                    distance = smooth_min(distance, obj_distance, smooth_k);
+                else if (obj_distance < distance)
+                    distance = obj_distance;
             }
             shade = rs_min(shade, smoothstep(rs_clamp(shading_k * distance / distance_travelled, 0.0f, 1.0f)));
             distance_travelled += distance;
@@ -696,6 +736,7 @@ struct Engine {
     Vec3 camera_position;
     PointLight light;
     int map_size = 8;
+    float smooth_k = 0.0f;  // EXTENSION, see Ray::smooth_k
     std::vector<std::shared_ptr<Texture>> textures;
     std::string error;
     Counters counters;  // merged totals
@@ -704,6 +745,7 @@ struct Engine {
     Colour cast_sight_ray(const Vec3 &position, const Vec3 &direction, uint64_t depth) const {
         CNT_MAX(max_depth, depth);
         Ray ray{position, direction};
+        ray.smooth_k = smooth_k;
         uint64_t has_hit = ray.march(objects, NONE);
         if (has_hit == NONE) {
             CNT(sky_hits, 1);
@@ -737,6 +779,7 @@ struct Engine {
         phong_ds(n, vector_to_light, distance_to_light, light.intensity, object_mat, direction, diffuse, specular);
 
         Ray shadow{position, vector_to_light};
+        shadow.smooth_k = smooth_k;
         float shade = shadow.smooth_shadow_march(objects, obj_index, distance_to_light, 16.0f);
 
         Colour final_colour = ambient + object_colour * (shade * (diffuse + specular));
@@ -823,6 +866,7 @@ struct Engine {
             for (int x = 0; x < W; x++) {
                 Vec3 dir = pixel_direction(pose, W, H, x, y_inv);
                 Ray ray{camera_position, dir};
+                ray.smooth_k = smooth_k;
                 uint64_t h = ray.march(objects, NONE);
                 size_t i = (size_t)y_inv * W + x;
                 hit[i] = (h == NONE) ? -1 : (int32_t)h;
@@ -881,6 +925,7 @@ struct Engine {
                     float distance_to_light = vector_to_light.mag();
                     vector_to_light = vector_to_light / distance_to_light;
                     Ray shadow_ray{origin, vector_to_light};
+                    shadow_ray.smooth_k = smooth_k;
                     (void)shadow_ray.march(objects, obj_index);
                     if ((shadow_ray.position - origin).mag() < (distance_to_light + 3.0f * SMALL_DISTANCE)) continue;
                     Vec3 nrm = object.calculate_normal(origin);
@@ -948,6 +993,7 @@ struct Engine {
 
                     // `3.0 * SMALL_DISTANCE * -v` = (3.0*0.001) * (-v)
                     Ray shadow_ray{light_source + ((-vector_to_light) * (3.0f * SMALL_DISTANCE)), -vector_to_light};
+                    shadow_ray.smooth_k = smooth_k;
                     uint64_t hit = shadow_ray.march(objects, NONE, true);
                     if (hit != NONE) {
                         if (hit != obj_eng_index) {
@@ -1115,6 +1161,17 @@ int orc_add_plane(void *h, const float *normal, float distance, const float *mat
     e->objects.push_back(std::move(s));
     return (int)e->objects.size() - 1;
 }
+int orc_add_box(void *h, const float *pos, const float *half, const float *mat, const float *colour) {
+    Engine *e = static_cast<Engine *>(h);
+    auto s = std::make_unique<Box>(e->map_size);
+    s->position = Vec3(pos[0], pos[1], pos[2]);
+    s->half = Vec3(half[0], half[1], half[2]);
+    set_common(*s, mat, colour);
+    e->objects.push_back(std::move(s));
+    return (int)e->objects.size() - 1;
+}
+void orc_set_smooth_union(void *h, float k) { static_cast<Engine *>(h)->smooth_k = k; }
+float orc_kat_smooth_min(float a, float b, float k) { return smooth_min(a, b, k); }
 void orc_set_light(void *h, const float *pos, float intensity) {
     Engine *e = static_cast<Engine *>(h);
     e->light.position = Vec3(pos[0], pos[1], pos[2]);
@@ -1240,12 +1297,14 @@ void orc_kat_normal(void *h, int obj, const float *p, float *out) {
 // returns hit index or -1; pos_io is updated to the final ray position
 int orc_kat_march(void *h, float *pos_io, const float *dir, int ignore, int radiosity) {
     Ray r{Vec3(pos_io[0], pos_io[1], pos_io[2]), Vec3(dir[0], dir[1], dir[2])};
+    r.smooth_k = static_cast<Engine *>(h)->smooth_k;
     uint64_t hit = r.march(static_cast<Engine *>(h)->objects, ignore < 0 ? NONE : (uint64_t)ignore, radiosity != 0);
     for (int i = 0; i < 3; i++) pos_io[i] = r.position.l[i];
     return hit == NONE ? -1 : (int)hit;
 }
 float orc_kat_shadow(void *h, const float *pos, const float *dir, int ignore, float light_dist, float k) {
     Ray r{Vec3(pos[0], pos[1], pos[2]), Vec3(dir[0], dir[1], dir[2])};
+    r.smooth_k = static_cast<Engine *>(h)->smooth_k;
     return r.smooth_shadow_march(static_cast<Engine *>(h)->objects, (uint64_t)ignore, light_dist, k);
 }
 void orc_kat_phong(const float *n, const float *l, float dist, float intensity, const float *mat, const float *view,

@@ -1,5 +1,6 @@
 """MI355X-native ray-marching hot path: scene types, Engine and multi-GPU helpers."""
 from .scene import (  # noqa: F401
+    Box,
     Material,
     Plane,
     PointLight,
@@ -15,6 +16,7 @@ from .scene import (  # noqa: F401
 )
 
 __all__ = [
+    "Box",
     "Engine",
     "Material",
     "Plane",

@@ -34,6 +34,8 @@ SIGNATURES = {
     "rm_scene_add_yplane": (c_int, [c_void_p, c_float, c_float, POINTER(Material), _F3, c_int]),
     "rm_scene_add_zplane": (c_int, [c_void_p, c_float, c_float, POINTER(Material), _F3]),
     "rm_scene_add_plane": (c_int, [c_void_p, _F3, c_float, POINTER(Material), _F3]),
+    "rm_scene_add_box": (c_int, [c_void_p, _F3, _F3, POINTER(Material), _F3]),
+    "rm_scene_set_smooth_union": (c_int, [c_void_p, c_float]),
     "rm_scene_set_light": (c_int, [c_void_p, _F3, c_float]),
     "rm_scene_set_camera": (c_int, [c_void_p, _F3]),
     "rm_engine_create": (c_void_p, [c_void_p, c_int, c_int, c_int, c_int]),

@@ -68,15 +68,28 @@ RM_DEV int sat_i32(float f) {
     return (int)f;
 }
 
-// objects.rs:334, 295, 275, 315, 261
-RM_DEV float sdf_eval(int type, float g0, float g1, float g2, float g3, V3 p) {
+// objects.rs:334, 295, 275, 315, 261; T_BOX: the commented-out box of objects.rs:370-380 with
+// centre and half extents as parameters (an extension, evaluated in the order written there)
+RM_DEV float sdf_eval(int type, const Geom &g, V3 p) {
     switch (type) {
-        case T_SPHERE: return mag(p - v3(g0, g1, g2)) - g3;
-        case T_XPLANE: return g1 * (p.x - g0);
-        case T_YPLANE: return g1 * (p.y - g0);
-        case T_ZPLANE: return g1 * (p.z - g0);
-        default: return ((p.x * g0 + p.y * g1) + p.z * g2) - g3;
+        case T_SPHERE: return mag(p - v3(g.p[0], g.p[1], g.p[2])) - g.p[3];
+        case T_XPLANE: return g.p[1] * (p.x - g.p[0]);
+        case T_YPLANE: return g.p[1] * (p.y - g.p[0]);
+        case T_ZPLANE: return g.p[1] * (p.z - g.p[0]);
+        case T_PLANE: return ((p.x * g.p[0] + p.y * g.p[1]) + p.z * g.p[2]) - g.p[3];
+        default: {
+            V3 q = v3(fabsf(p.x - g.p[0]) - g.p[3], fabsf(p.y - g.p[1]) - g.p[4], fabsf(p.z - g.p[2]) - g.p[5]);
+            V3 r = v3(rs_max(q.x, 0.0f), rs_max(q.y, 0.0f), rs_max(q.z, 0.0f));
+            return mag(r) + rs_min(rs_max(q.x, rs_max(q.y, q.z)), 0.0f);
+        }
     }
+}
+
+// Polynomial smooth minimum for "smooth unions" (an extension: the reference's union is the hard
+// minimum of ray.rs:23-33).
+RM_DEV float smooth_min(float a, float b, float k) {
+    float h = rs_max(k - fabsf(a - b), 0.0f) / k;
+    return rs_min(a, b) - h * h * k * (1.0f / 4.0f);
 }
 
 // Correctly rounded square root.  v_sqrt_f32 is within one ulp; the two fused
@@ -203,6 +216,45 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, bool active = true) {
         if (!far && active) d = rs_min(d, ign.mask(oi, sqrt_rn(m) - r));
     });
     return d;
+}
+
+// The same for a scene walked in object order (boxes, smooth unions).  With smooth_k > 0 the
+// distances are folded with smooth_min in index order, which is part of the result.
+struct SceneOrderedAcc {
+    const OrderedScene &g;
+};
+RM_DEV SceneOrderedAcc acc_of(const OrderedScene &g) { return SceneOrderedAcc{g}; }
+
+template <class IGN>
+RM_DEV float scene_min(const SceneOrderedAcc &sc, V3 p, const IGN &ign, bool active = true) {
+    (void)active;
+    const float k = sc.g.smooth_k;
+    float d = __builtin_inff();
+    for (int i = 0; i < sc.g.n; i++) {
+        if (ign.skip(i)) continue;
+        const float s = ign.mask(i, sdf_eval(sc.g.type[i], sc.g.geom[i], p));
+        if (k > 0.0f)
+            d = smooth_min(d, s, k);
+        else if (s < d)
+            d = s;
+    }
+    return d;
+}
+
+// The hit object: smallest own distance, lowest index on ties (with or without blending).
+template <class IGN>
+RM_DEV int closest_index(const SceneOrderedAcc &sc, V3 p, float, const IGN &ign) {
+    float best = __builtin_inff();
+    int idx = -1;
+    for (int i = 0; i < sc.g.n; i++) {
+        if (ign.skip(i)) continue;
+        const float s = ign.mask(i, sdf_eval(sc.g.type[i], sc.g.geom[i], p));
+        if (s < best) {
+            best = s;
+            idx = i;
+        }
+    }
+    return idx;
 }
 
 // Lowest object index whose sdf at p equals d (every object evaluated exactly).
@@ -341,13 +393,12 @@ RM_DEV float smooth_shadow_march(const SC &sc, V3 pos, V3 dir, int ignore, float
 
 // objects.rs:135-141 for a per-lane object
 RM_DEV V3 calculate_normal(int type, const Geom &g, V3 p) {
-    float g0 = g.p[0], g1 = g.p[1], g2 = g.p[2], g3 = g.p[3];
-    float gx = sdf_eval(type, g0, g1, g2, g3, v3(p.x + STEP_SIZE, p.y + 0.0f, p.z + 0.0f)) -
-               sdf_eval(type, g0, g1, g2, g3, v3(p.x - STEP_SIZE, p.y - 0.0f, p.z - 0.0f));
-    float gy = sdf_eval(type, g0, g1, g2, g3, v3(p.x + 0.0f, p.y + STEP_SIZE, p.z + 0.0f)) -
-               sdf_eval(type, g0, g1, g2, g3, v3(p.x - 0.0f, p.y - STEP_SIZE, p.z - 0.0f));
-    float gz = sdf_eval(type, g0, g1, g2, g3, v3(p.x + 0.0f, p.y + 0.0f, p.z + STEP_SIZE)) -
-               sdf_eval(type, g0, g1, g2, g3, v3(p.x - 0.0f, p.y - 0.0f, p.z - STEP_SIZE));
+    float gx = sdf_eval(type, g, v3(p.x + STEP_SIZE, p.y + 0.0f, p.z + 0.0f)) -
+               sdf_eval(type, g, v3(p.x - STEP_SIZE, p.y - 0.0f, p.z - 0.0f));
+    float gy = sdf_eval(type, g, v3(p.x + 0.0f, p.y + STEP_SIZE, p.z + 0.0f)) -
+               sdf_eval(type, g, v3(p.x - 0.0f, p.y - STEP_SIZE, p.z - 0.0f));
+    float gz = sdf_eval(type, g, v3(p.x + 0.0f, p.y + 0.0f, p.z + STEP_SIZE)) -
+               sdf_eval(type, g, v3(p.x - 0.0f, p.y - 0.0f, p.z - STEP_SIZE));
     return normalized(v3(gx, gy, gz));
 }
 

@@ -358,7 +358,7 @@ static int fail(int code, const std::string &msg) {
 
 struct HostObject {
     int type;
-    float p[4];
+    float p[8];
     rm_material mat;
     float colour[3];
     int texture;
@@ -376,6 +376,7 @@ struct rm_scene {
     float light[3] = {0.0f, 0.0f, 0.0f};
     float intensity = 1.0f;
     float camera[3] = {0.0f, 0.0f, 0.0f};
+    float smooth_k = 0.0f;  // 0 = hard minimum (the reference's union)
 };
 
 struct rm_engine {
@@ -389,7 +390,8 @@ struct rm_engine {
 
     // device-resident scene
     int n = 0, n_lm = 0, n_patches = 0;
-    int tier = 2;  // -1: GroupedTierX, 0: GroupedTierA, 1: GroupedTierB, 2: GroupedLarge
+    int tier = 2;  // -1: GroupedTierX, 0: GroupedTierA, 1: GroupedTierB, 2: GroupedLarge, 3: OrderedScene
+    OrderedScene ordered_scene;
     GroupedTierX tier_x;
     GroupedTierA tier_a;
     GroupedTierB tier_b;
@@ -503,10 +505,11 @@ static int engine_upload(rm_engine *e) {
     // objects grouped by type for the march loops (original indices kept alongside)
     std::vector<int> gi_sph, gi_ax[3], gi_gp;
     std::vector<float> g_sph, g_ax[3], g_gp;
+    int n_boxes = 0;
     for (int i = 0; i < e->n; i++) {
         const HostObject &o = s.objects[i];
         type[i] = o.type;
-        memcpy(geom[i].p, o.p, sizeof(float) * 4);
+        memcpy(geom[i].p, o.p, sizeof(float) * 8);
         ShadeRec r;
         memset(&r, 0, sizeof(r));
         r.ambient = o.mat.ambient;
@@ -521,7 +524,7 @@ static int engine_upload(rm_engine *e) {
         r.type = o.type;
         r.texture = o.texture;
         r.textured = (o.type == T_YPLANE && !(o.p[0] > 0.0f)) ? 1 : 0;  // objects.rs:268
-        if (o.type != T_PLANE) {
+        if (o.type != T_PLANE && o.type != T_BOX) {
             r.lm_slot = (int)e->patch_obj.size();
             e->lm_slot[i] = r.lm_slot;
             e->patch_obj.push_back(i);
@@ -542,9 +545,12 @@ static int engine_upload(rm_engine *e) {
                 g_ax[a].insert(g_ax[a].end(), o.p, o.p + 2);
                 break;
             }
-            default:
+            case T_PLANE:
                 gi_gp.push_back(i);
                 g_gp.insert(g_gp.end(), o.p, o.p + 4);
+                break;
+            default:
+                n_boxes++;
                 break;
         }
     }
@@ -576,7 +582,9 @@ static int engine_upload(rm_engine *e) {
     memset(&e->tier_a, 0, sizeof(e->tier_a));
     memset(&e->tier_b, 0, sizeof(e->tier_b));
     memset(&e->tier_x, 0, sizeof(e->tier_x));
-    if (gi_sph.size() == 2 && gi_ax[0].size() == 2 && gi_ax[1].size() == 2 && gi_ax[2].size() == 2 && gi_gp.empty()) {
+    if (n_boxes > 0 || s.smooth_k > 0.0f) {
+        e->tier = 3;  // evaluation order matters or the scene holds boxes: ordered walk
+    } else if (gi_sph.size() == 2 && gi_ax[0].size() == 2 && gi_ax[1].size() == 2 && gi_ax[2].size() == 2 && gi_gp.empty()) {
         e->tier = -1;
         fill(e->tier_x);
     } else if (fits(GroupedTierA::kSpheres, GroupedTierA::kAxis, GroupedTierA::kPlanes)) {
@@ -630,6 +638,7 @@ static int engine_upload(rm_engine *e) {
     HIP_TRY(hipMemcpy(e->d_type, type.data(), sizeof(int) * e->n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_geom, geom.data(), sizeof(Geom) * e->n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_shade, shade.data(), sizeof(ShadeRec) * e->n, hipMemcpyHostToDevice));
+    e->ordered_scene = OrderedScene{e->n, e->d_type, e->d_geom, s.smooth_k};
 
     std::vector<TextureRec> tex(s.textures.size());
     e->d_texels.assign(s.textures.size(), nullptr);
@@ -686,6 +695,9 @@ static void engine_free(rm_engine *e) {
             hipLaunchKernelGGL((KERNEL<GroupedTierA>), grid, block, 0, (e)->stream, __VA_ARGS__, (e)->tier_a); \
         else if ((e)->tier == 1)                                                                              \
             hipLaunchKernelGGL((KERNEL<GroupedTierB>), grid, block, 0, (e)->stream, __VA_ARGS__, (e)->tier_b); \
+        else if ((e)->tier == 3)                                                                              \
+            hipLaunchKernelGGL((KERNEL<OrderedScene>), grid, block, 0, (e)->stream, __VA_ARGS__,              \
+                               (e)->ordered_scene);                                                           \
         else                                                                                                  \
             hipLaunchKernelGGL((KERNEL<GroupedLarge>), grid, block, 0, (e)->stream, __VA_ARGS__,              \
                                (e)->large_scene);                                                             \
@@ -765,13 +777,13 @@ int rm_texture_create_rgb8(rm_scene *scene, const uint8_t *rgb, int width, int h
     return (int)scene->textures.size() - 1;
 }
 
-static int add_object(rm_scene *scene, int type, const float p[4], const rm_material *m, const float colour[3],
+static int add_object(rm_scene *scene, int type, const float p[8], const rm_material *m, const float colour[3],
                       int texture) {
     if (!scene || !m || !colour) return -fail(RM_ERR_INVALID, "NULL argument");
     if (scene->objects.size() >= RM_MAX_OBJECTS) return -fail(RM_ERR_LIMIT, "too many objects");
     HostObject o;
     o.type = type;
-    memcpy(o.p, p, sizeof(float) * 4);
+    memcpy(o.p, p, sizeof(float) * 8);
     o.mat = *m;
     memcpy(o.colour, colour, sizeof(float) * 3);
     o.texture = texture;
@@ -782,29 +794,40 @@ static int add_object(rm_scene *scene, int type, const float p[4], const rm_mate
 int rm_scene_add_sphere(rm_scene *scene, const float position[3], float radius, const rm_material *material,
                         const float colour[3]) {
     if (!position) return -fail(RM_ERR_INVALID, "NULL position");
-    float p[4] = {position[0], position[1], position[2], radius};
+    float p[8] = {position[0], position[1], position[2], radius};
     return add_object(scene, T_SPHERE, p, material, colour, -1);
 }
 int rm_scene_add_xplane(rm_scene *scene, float x, float dir, const rm_material *material, const float colour[3]) {
-    float p[4] = {x, dir, 0.0f, 0.0f};
+    float p[8] = {x, dir};
     return add_object(scene, T_XPLANE, p, material, colour, -1);
 }
 int rm_scene_add_yplane(rm_scene *scene, float y, float dir, const rm_material *material, const float colour[3],
                         int texture) {
     if (!scene || texture < 0 || texture >= (int)scene->textures.size())
         return -fail(RM_ERR_INVALID, "YPlane::new takes a texture (objects.rs:236)");
-    float p[4] = {y, dir, 0.0f, 0.0f};
+    float p[8] = {y, dir};
     return add_object(scene, T_YPLANE, p, material, colour, texture);
 }
 int rm_scene_add_zplane(rm_scene *scene, float z, float dir, const rm_material *material, const float colour[3]) {
-    float p[4] = {z, dir, 0.0f, 0.0f};
+    float p[8] = {z, dir};
     return add_object(scene, T_ZPLANE, p, material, colour, -1);
 }
 int rm_scene_add_plane(rm_scene *scene, const float normal[3], float distance, const rm_material *material,
                        const float colour[3]) {
     if (!normal) return -fail(RM_ERR_INVALID, "NULL normal");
-    float p[4] = {normal[0], normal[1], normal[2], distance};
+    float p[8] = {normal[0], normal[1], normal[2], distance};
     return add_object(scene, T_PLANE, p, material, colour, -1);
+}
+int rm_scene_add_box(rm_scene *scene, const float position[3], const float half_extent[3], const rm_material *material,
+                     const float colour[3]) {
+    if (!position || !half_extent) return -fail(RM_ERR_INVALID, "NULL argument");
+    float p[8] = {position[0], position[1], position[2], half_extent[0], half_extent[1], half_extent[2]};
+    return add_object(scene, T_BOX, p, material, colour, -1);
+}
+int rm_scene_set_smooth_union(rm_scene *scene, float k) {
+    if (!scene || !(k >= 0.0f)) return fail(RM_ERR_INVALID, "smooth union width must be >= 0");
+    scene->smooth_k = k;
+    return RM_OK;
 }
 int rm_scene_set_light(rm_scene *scene, const float position[3], float intensity) {
     if (!scene || !position) return fail(RM_ERR_INVALID, "NULL argument");

@@ -4,7 +4,7 @@
 
 namespace rm {
 
-enum ObjType : int { T_SPHERE = 0, T_XPLANE = 1, T_YPLANE = 2, T_ZPLANE = 3, T_PLANE = 4 };
+enum ObjType : int { T_SPHERE = 0, T_XPLANE = 1, T_YPLANE = 2, T_ZPLANE = 3, T_PLANE = 4, T_BOX = 5 };
 
 // engine.rs:12-14
 constexpr float MAX_MARCH_DISTANCE = 50.0f;
@@ -17,12 +17,13 @@ constexpr float SHADOW_K = 16.0f;
 
 constexpr int MAX_DEPTH = 16;  // explicit reflection stack (the reference recurses without bound)
 
-// Geometry of one object, 16 bytes.
+// Geometry of one object, 32 bytes.
 //   sphere      : cx, cy, cz, radius
-//   axis plane  : offset, dir, -, -
+//   axis plane  : offset, dir
 //   plane       : nx, ny, nz, distance
+//   box         : cx, cy, cz, hx, hy, hz   (centre, half extents)
 struct Geom {
-    float p[4];
+    float p[8];
 };
 
 // Everything shading needs about one object, 64 bytes, indexed per lane.
@@ -79,6 +80,16 @@ struct GroupedLarge {
     const float *sph;  // [n_sph][4]
     const float *ax[3];  // [n][2]
     const float *gp;     // [n_gp][4]
+};
+
+// A scene walked in object order with a per-object type switch: the path for scenes that hold
+// boxes or blend distances with a smooth minimum (both extensions of the reference's object set),
+// where the order of evaluation is part of the result.
+struct OrderedScene {
+    int n;
+    const int *type;   // [n]
+    const Geom *geom;  // [n]
+    float smooth_k;    // 0 = hard minimum
 };
 
 struct SceneView {

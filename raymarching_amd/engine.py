@@ -47,6 +47,12 @@ class _SceneBuilder:
     def add_plane(self, normal, distance, mat, colour):
         self._obj(self.lib.rm_scene_add_plane(self.handle, _lib.f3(normal), distance, _lib.Material(*mat), _lib.f3(colour)), "rm_scene_add_plane")
 
+    def add_box(self, pos, half, mat, colour):
+        self._obj(self.lib.rm_scene_add_box(self.handle, _lib.f3(pos), _lib.f3(half), _lib.Material(*mat), _lib.f3(colour)), "rm_scene_add_box")
+
+    def set_smooth_union(self, k):
+        _lib.check(self.lib.rm_scene_set_smooth_union(self.handle, k), "rm_scene_set_smooth_union")
+
     def set_light(self, pos, intensity):
         _lib.check(self.lib.rm_scene_set_light(self.handle, _lib.f3(pos), intensity), "rm_scene_set_light")
 

@@ -131,6 +131,16 @@ class ZPlane:
 
 
 @dataclass
+class Box:
+    """Extension: the commented-out box of objects.rs:370-380 with centre and half extents."""
+
+    position: Vec3
+    half_extent: Vec3
+    material: Material
+    colour: Vec3
+
+
+@dataclass
 class PointLight:
     """objects.rs:205-209"""
 
@@ -145,6 +155,7 @@ class Scene:
     objects: List[object]
     camera_position: Vec3
     light: PointLight
+    smooth_union: float = 0.0  # extension: > 0 blends object distances (0 = the reference's hard minimum)
 
 
 def construct_objects(texture_path: str) -> List[object]:
@@ -204,16 +215,22 @@ def build_scene(backend, scene: Scene):
             backend.add_zplane(obj.z, obj.dir, mat, obj.colour)
         elif isinstance(obj, Plane):
             backend.add_plane(obj.normal, obj.distance, mat, obj.colour)
+        elif isinstance(obj, Box):
+            backend.add_box(obj.position, obj.half_extent, mat, obj.colour)
         else:
             raise TypeError(f"unknown object type {type(obj).__name__}")
     backend.set_light(scene.light.position, scene.light.intensity)
     backend.set_camera(scene.camera_position)
+    if scene.smooth_union:
+        backend.set_smooth_union(scene.smooth_union)
 
 
-def stress_scene(n_spheres: int = 250, seed: int = 0xC0FFEE, texture_path: Optional[str] = None) -> Scene:
+def stress_scene(n_spheres: int = 250, seed: int = 0xC0FFEE, texture_path: Optional[str] = None, boxes: bool = False,
+                 smooth_union: float = 0.0) -> Scene:
     """A seed-fixed synthetic scene: the default room (six axis planes, textured floor) filled with
-    `n_spheres` small spheres of mixed materials.  It exercises the large-scene path (geometry in
-    global memory) and deep divergence; it has no counterpart in the reference."""
+    `n_spheres` small primitives of mixed materials (every third one a box if `boxes`), optionally
+    blended with a smooth union.  It exercises the large-scene and ordered paths and deep
+    divergence; it has no counterpart in the reference."""
     if texture_path is None:
         texture_path = default_texture_path()
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -231,13 +248,23 @@ def stress_scene(n_spheres: int = 250, seed: int = 0xC0FFEE, texture_path: Optio
             placed.append((c, r))
     for i, (c, r) in enumerate(placed):
         kind = i % 4
+        # A reflection ray starts 3e-3 off the surface (engine.rs:237).  Inside the blend zone of a
+        # smooth union that is still "on" the surface, so the ray hits its own object again and the
+        # recursion runs hundreds deep.  Blended scenes therefore get no reflective materials.
+        refl = 0.0 if smooth_union > 0.0 else 1.0
         if kind == 0:
-            mat = Material(0.05, 0.3, 0.2, 16.0, 0.5, 0.0)  # half mirror
+            mat = Material(0.05, 0.3, 0.2, 16.0, 0.5 * refl, 0.0)  # half mirror
         elif kind == 1:
-            mat = Material(0.1, 1.0, 0.9, 32.0, 0.25, 0.0)  # glossy
+            mat = Material(0.1, 1.0, 0.9, 32.0, 0.25 * refl, 0.0)  # glossy
         else:
             mat = Material(0.25, 1.0, 0.0, 4.0, 0.0, 0.0)  # matt
-        objects.append(Sphere((float(c[0]), float(c[1]), float(c[2])), r, mat, palette[i % len(palette)]))
+        centre = (float(c[0]), float(c[1]), float(c[2]))
+        if boxes and i % 3 == 2:
+            # inscribed in the sphere that was placed, so the gaps between primitives stay
+            h = r / np.sqrt(3.0)
+            objects.append(Box(centre, (float(h * 1.2), float(h * 0.9), float(h * 0.8)), mat, palette[i % len(palette)]))
+        else:
+            objects.append(Sphere(centre, r, mat, palette[i % len(palette)]))
     objects += [
         YPlane(-2.0, 1.0, basic, SOFT_GRAY, wood),
         YPlane(4.0, -1.0, basic, SOFT_GRAY, wood),
@@ -246,4 +273,5 @@ def stress_scene(n_spheres: int = 250, seed: int = 0xC0FFEE, texture_path: Optio
         ZPlane(2.0, -1.0, basic, SOFT_GRAY),
         ZPlane(-4.0, 1.0, basic, SOFT_GRAY),
     ]
-    return Scene(objects=objects, camera_position=(0.0, 0.5, -3.5), light=PointLight((2.0, -1.0, 1.5), 3.5))
+    return Scene(objects=objects, camera_position=(0.0, 0.5, -3.5), light=PointLight((2.0, -1.0, 1.5), 3.5),
+                 smooth_union=smooth_union)

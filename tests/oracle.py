@@ -49,6 +49,10 @@ def load(counting=False):
     lib.orc_add_yplane.argtypes = [c_void_p, c_float, c_float, _F, _F, c_int]
     lib.orc_add_zplane.argtypes = [c_void_p, c_float, c_float, _F, _F]
     lib.orc_add_plane.argtypes = [c_void_p, _F, c_float, _F, _F]
+    lib.orc_add_box.argtypes = [c_void_p, _F, _F, _F, _F]
+    lib.orc_set_smooth_union.argtypes = [c_void_p, c_float]
+    lib.orc_kat_smooth_min.restype = c_float
+    lib.orc_kat_smooth_min.argtypes = [c_float, c_float, c_float]
     lib.orc_set_light.argtypes = [c_void_p, _F, c_float]
     lib.orc_set_camera.argtypes = [c_void_p, _F]
     lib.orc_get_camera.argtypes = [c_void_p, _F]
@@ -126,6 +130,12 @@ class OracleEngine:
 
     def add_plane(self, normal, distance, mat, colour):
         self.lib.orc_add_plane(self.handle, _fa(normal), distance, _fa(mat), _fa(colour))
+
+    def add_box(self, pos, half, mat, colour):
+        self.lib.orc_add_box(self.handle, _fa(pos), _fa(half), _fa(mat), _fa(colour))
+
+    def set_smooth_union(self, k):
+        self.lib.orc_set_smooth_union(self.handle, k)
 
     def set_light(self, pos, intensity):
         self.lib.orc_set_light(self.handle, _fa(pos), intensity)

@@ -5,18 +5,18 @@ import numpy as np
 import pytest
 
 from conftest import assert_frames_match, make_oracle
-from raymarching_amd.scene import (SOFT_GRAY, SOFT_GREEN, SOFT_RED, SOFT_YELLOW, WHITE, Material, Plane, PointLight,
-                                   Scene, Sphere, XPlane, YPlane, ZPlane, default_scene, stress_scene)
+from raymarching_amd.scene import (SOFT_GRAY, SOFT_GREEN, SOFT_RED, SOFT_YELLOW, WHITE, Box, Material, Plane,
+                                   PointLight, Scene, Sphere, XPlane, YPlane, ZPlane, default_scene, stress_scene)
 
 pytestmark = pytest.mark.gpu
 
 W, H = 320, 240
 
 
-def _room(extra, drop=()):
+def _room(extra, drop=(), smooth=0.0):
     base = default_scene()
     objs = [o for i, o in enumerate(base.objects) if i not in drop]
-    return Scene(objects=list(extra) + objs, camera_position=base.camera_position, light=base.light)
+    return Scene(objects=list(extra) + objs, camera_position=base.camera_position, light=base.light, smooth_union=smooth)
 
 
 GLOSSY = Material(0.1, 1.0, 0.9, 32.0, 0.25, 0.0)
@@ -31,6 +31,11 @@ SCENES = {
                              Plane((0.0, 0.70710678, -0.70710678), -2.0, MATT, SOFT_YELLOW)]),
     # five spheres: beyond every by-value tier -> geometry in global memory
     "large_small": lambda: _room([Sphere((-2.0 + i, 2.0, 1.0), 0.4, [MIRROR, GLOSSY, MATT][i % 3], WHITE) for i in range(3)]),
+    # boxes (hard minimum) and a smooth union of the default scene: the ordered path
+    "boxes": lambda: _room([Box((0.0, 1.0, 0.5), (0.5, 0.3, 0.4), GLOSSY, SOFT_RED), Box((-2.0, -1.5, 1.0), (0.4, 0.5, 0.4), MATT, SOFT_GREEN)]),
+    # (matt spheres: a reflective surface inside a blend zone re-hits itself and recurses hundreds deep)
+    "smooth_union": lambda: _room([Sphere((-1.2, -1.0, 0.1), 1.0, MATT, WHITE), Sphere((1.0, -1.0, -0.7), 1.0, Material(0.1, 1.0, 0.9, 32.0, 0.0, 0.0), SOFT_YELLOW),
+                                   Box((0.2, -1.6, 0.6), (0.5, 0.4, 0.4), MATT, SOFT_RED)], drop=(0, 1), smooth=0.3),
     # open scene: two planes removed, primary rays reach the sky (engine.rs:141)
     "open_sky": lambda: _room([], drop=(3, 6)),
 }
@@ -47,7 +52,7 @@ def _compare(scene, w=W, h=H, pose=(0, 0, (0.0, 0.0, 0.0), 0), lightmaps=True):
         u, v = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
         lm = np.stack([0.10 + 0.02 * u, 0.12 + 0.01 * v, 0.08 + 0.01 * (u + v)], axis=-1).astype(np.float32)
         for i in range(eng.n_objects):
-            if not isinstance(scene.objects[i], Plane):
+            if not isinstance(scene.objects[i], (Plane, Box)):
                 eng.set_lightmap(i, lm)
                 ora.set_lightmap(i, lm)
     if lightmaps:
@@ -56,7 +61,7 @@ def _compare(scene, w=W, h=H, pose=(0, 0, (0.0, 0.0, 0.0), 0), lightmaps=True):
         eng.compute_lightmaps(2)
         ora.compute_lightmaps(2)
         for i in range(eng.n_objects):
-            if not isinstance(scene.objects[i], Plane):
+            if not isinstance(scene.objects[i], (Plane, Box)):
                 assert np.array_equal(eng.get_lightmap(i).view(np.uint32), ora.get_lightmap(i).view(np.uint32)), i
     hit_g, steps_g, pos_g = eng.trace_primary()
     hit_o, steps_o, pos_o = ora.trace_primary(w, h)
@@ -72,7 +77,7 @@ def _compare(scene, w=W, h=H, pose=(0, 0, (0.0, 0.0, 0.0), 0), lightmaps=True):
 @pytest.mark.parametrize("name", sorted(SCENES))
 def test_scene_tiers(name):
     scene = SCENES[name]()
-    has_plane = any(isinstance(o, Plane) for o in scene.objects)
+    has_plane = any(isinstance(o, (Plane, Box)) for o in scene.objects)
     got, ref, st, hit = _compare(scene, lightmaps=not has_plane)
     mx, exact = assert_frames_match(got, ref, name)
     print(f"{name}: max|d|={mx} exact={exact:.5%} caps={st}")
@@ -94,6 +99,16 @@ def test_stress_scene_250_spheres():
     # reflection chains between the many spheres run deeper than the 16-frame stack; what is cut
     # has been attenuated below one float32 ulp of the pixel by then, and the cuts are counted
     assert st["lightmap_oob"] == 0
+
+
+def test_mixed_stress_scene_with_smooth_unions():
+    """256 mixed primitives (spheres, boxes, the room) blended with a smooth union: the shape of the
+    benchmark's stress configuration at a size the CPU oracle renders in seconds."""
+    scene = stress_scene(250, boxes=True, smooth_union=0.08)
+    got, ref, st, _ = _compare(scene, 192, 144, lightmaps=False)
+    mx, exact = assert_frames_match(got, ref, "mixed stress")
+    print(f"mixed stress: max|d|={mx} exact={exact:.5%} caps={st}")
+    assert st["depth_cap_hits"] == 0
 
 
 def test_march_cap_counts_and_binds(scene):
