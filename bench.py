@@ -37,8 +37,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the CPU baseline leg")
     ap.add_argument("--no-overlap", action="store_true", help="wait for each frame's all-gather before the next render")
-    ap.add_argument("--workload", choices=["render", "radiosity"], default="render",
-                    help="render: the headline frame benchmark; radiosity: Engine::compute_lightmaps, patch-sharded")
+    ap.add_argument("--workload", choices=["render", "radiosity", "stress"], default="render",
+                    help="render: the headline frame benchmark; radiosity: Engine::compute_lightmaps, patch-sharded; "
+                    "stress: 256 mixed primitives with smooth unions at 7680x4320, march cap 1024")
     ap.add_argument("--map-size", type=int, default=8, help="lightmap edge for --workload radiosity (8 in the reference)")
     return ap.parse_args()
 
@@ -193,10 +194,28 @@ def main():
 
     W, H = args.width, args.height
     scene = default_scene()
+    if args.workload == "stress":
+        from raymarching_amd.scene import stress_scene
+
+        if (W, H) == (3840, 2160):
+            W, H = 7680, 4320
+        scene = stress_scene(250, boxes=True, smooth_union=0.08)
+        args.no_cpu_baseline = True  # minutes per frame on the CPU; parity is covered by the GPU tests at small sizes
     eng = Engine(scene, W, H, device=local_rank)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
-    eng.compute_lightmaps(4)  # main.rs:73: once, before the frame loop (not timed)
+    if args.workload == "stress":
+        # boxes have no lightmap parameterisation: a fixed smooth pattern stands in for the precompute
+        u, v = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
+        lm = np.stack([0.10 + 0.02 * u, 0.12 + 0.01 * v, 0.08 + 0.01 * (u + v)], axis=-1).astype(np.float32)
+        from raymarching_amd.scene import Box
+
+        for i, obj in enumerate(scene.objects):
+            if not isinstance(obj, Box):
+                eng.set_lightmap(i, lm)
+        eng.set_march_cap(1024)
+    else:
+        eng.compute_lightmaps(4)  # main.rs:73: once, before the frame loop (not timed)
     eng.input(0, 0, (0.0, 0.0, 0.0), 0)  # first-frame pose (main.rs:78-80,122)
 
     # Sharding: without FXAA rank r renders the 8-row strips r, r+N, r+2N, ... (even load however
@@ -307,7 +326,7 @@ def main():
     if rank == 0:
         rays = W * H
         ms_per_step = elapsed / args.steps * 1e3
-        counters = load_counters(W, H)
+        counters = load_counters(W, H) if args.workload == "render" else None
         roofline = None
         if counters is not None:
             band_share = (r1 - r0) / H  # flops are counted for the whole frame; a band is its share by rows
@@ -328,7 +347,7 @@ def main():
                 "note": "FP32 vector ALU bound (no MFMA, HBM traffic is 4 B per ray); strict IEEE parity forbids FMA contraction",
             }
         result = {
-            "metric": "primary Mrays/s at 4K" if (W, H) == (3840, 2160) else f"primary Mrays/s at {W}x{H}",
+            "metric": "primary Mrays/s at 4K" if (W, H) == (3840, 2160) and args.workload == "render" else f"primary Mrays/s at {W}x{H}",
             "value": rays / (elapsed / args.steps) / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -341,7 +360,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic: the reference's default scene (main.rs:154-193), first-frame pose, lightmaps from 4 radiosity bounces",
             "config": {
-                "workload": f"default scene {W}x{H}, march + shading + texture + lightmap + reflections" + (" + FXAA" if args.fxaa else ""),
+                "workload": (f"default scene {W}x{H}, march + shading + texture + lightmap + reflections" if args.workload == "render"
+                             else f"stress scene: 250 spheres and boxes + room, smooth union k=0.08, {W}x{H}, march cap 1024")
+                + (" + FXAA" if args.fxaa else ""),
                 "width": W,
                 "height": H,
                 "bands": world,

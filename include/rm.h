@@ -104,10 +104,12 @@ int rm_scene_add_plane(rm_scene *scene, const float normal[3], float distance, c
  * primitives with smooth unions" scene needs them):
  * - a box: the commented-out distance function of objects.rs:370-380 with centre and half
  *   extents as parameters; shaded like Plane above (no lightmap);
- * - smooth unions: with k > 0 the per-object distances of every march are folded in object
- *   order with the polynomial smooth minimum  min(a,b) - h*h*k/4, h = max(k-|a-b|,0)/k;
- *   the hit object stays the one with the smallest own distance.  k = 0 (default) is the
- *   reference's hard minimum (ray.rs:23-33). */
+ * - smooth unions: with k > 0 the per-object distances of every march are folded with the
+ *   polynomial smooth minimum  min(a,b) - h*h*k/4, h = max(k-|a-b|,0)/k.  The fold runs over the
+ *   objects grouped by type - X, Y, Z planes, generic planes, spheres, boxes - and by index
+ *   inside a group (the smooth minimum does not associate, so the order is part of the
+ *   definition).  The hit object stays the one with the smallest own distance.  k = 0
+ *   (default) is the reference's hard minimum (ray.rs:23-33). */
 int rm_scene_add_box(rm_scene *scene, const float position[3], const float half_extent[3],
                      const rm_material *material, const float colour[3]);
 int rm_scene_set_smooth_union(rm_scene *scene, float k);

@@ -597,7 +597,12 @@ static inline void count_sdf(int type, bool shadow) {
 struct Ray {
     Vec3 position, direction;
     uint64_t last_steps = 0;
-    float smooth_k = 0.0f;  // EXTENSION: > 0 blends the object distances with smooth_min, in index order
+    // EXTENSION: > 0 blends the object distances with smooth_min.  The smooth minimum does not
+    // associate, so the fold order is part of the definition: objects grouped by type (X, Y, Z
+    // planes, generic planes, spheres, boxes), by index inside a group - `order` holds that
+    // permutation.  With smooth_k = 0 the loops below are the reference's, in object order.
+    float smooth_k = 0.0f;
+    const std::vector<uint64_t> *order = nullptr;
 
     // ray.rs:15-42 and ray.rs:58-85 (radiosity=true also skips non-colliders)
     uint64_t march(const Objects &objects, uint64_t ignore_index, bool radiosity = false) {
@@ -610,7 +615,8 @@ struct Ray {
             float distance = std::numeric_limits<float>::infinity();
             float raw_best = std::numeric_limits<float>::infinity();
             uint64_t closest_object = NONE;
-            for (uint64_t i = 0; i < objects.size(); i++) {
+            for (uint64_t n = 0; n < objects.size(); n++) {
+                const uint64_t i = (smooth_k > 0.0f && order) ? (*order)[n] : n;
                 if (ignore_index == i) continue;
                 if (radiosity && !objects[i]->radiosity_collide()) continue;
                 count_sdf(objects[i]->type, false);
@@ -618,7 +624,7 @@ struct Ray {
                 if (smooth_k > 0.0f) {
                     // EXTENSION: the step length is the blended distance; the hit object is still
                     // the one with the smallest own distance (lowest index on ties)
-                    if (obj_distance < raw_best) {
+                    if (obj_distance < raw_best || (obj_distance == raw_best && i < closest_object)) {
                         raw_best = obj_distance;
                         closest_object = i;
                     }
@@ -661,7 +667,8 @@ struct Ray {
         for (uint32_t it = 0; it < MAX_SHAD_IT; it++) {
             CNT(shadow_steps, 1);
             float distance = std::numeric_limits<float>::infinity();
-            for (uint64_t i = 0; i < objects.size(); i++) {
+            for (uint64_t n = 0; n < objects.size(); n++) {
+                const uint64_t i = (smooth_k > 0.0f && order) ? (*order)[n] : n;
                 if (ignore_obj_index == i) continue;
                 count_sdf(objects[i]->type, true);
                 float obj_distance = objects[i]->sdf(position);
@@ -737,6 +744,17 @@ struct Engine {
     PointLight light;
     int map_size = 8;
     float smooth_k = 0.0f;  // EXTENSION, see Ray::smooth_k
+    mutable std::vector<uint64_t> fold_order;
+    const std::vector<uint64_t> *order() const {
+        if (fold_order.size() != objects.size()) {
+            static const int rank[6] = {4, 0, 1, 2, 3, 5};  // by ObjType: planes X,Y,Z, generic, spheres, boxes
+            fold_order.resize(objects.size());
+            for (uint64_t i = 0; i < objects.size(); i++) fold_order[i] = i;
+            std::stable_sort(fold_order.begin(), fold_order.end(),
+                             [&](uint64_t a, uint64_t b) { return rank[objects[a]->type] < rank[objects[b]->type]; });
+        }
+        return &fold_order;
+    }
     std::vector<std::shared_ptr<Texture>> textures;
     std::string error;
     Counters counters;  // merged totals
@@ -746,6 +764,7 @@ struct Engine {
         CNT_MAX(max_depth, depth);
         Ray ray{position, direction};
         ray.smooth_k = smooth_k;
+        ray.order = order();
         uint64_t has_hit = ray.march(objects, NONE);
         if (has_hit == NONE) {
             CNT(sky_hits, 1);
@@ -780,6 +799,7 @@ struct Engine {
 
         Ray shadow{position, vector_to_light};
         shadow.smooth_k = smooth_k;
+        shadow.order = order();
         float shade = shadow.smooth_shadow_march(objects, obj_index, distance_to_light, 16.0f);
 
         Colour final_colour = ambient + object_colour * (shade * (diffuse + specular));
@@ -830,6 +850,7 @@ struct Engine {
     // W*4-byte row per rendered row (row_step > 1 is a sampling aid for timing).
     void render_rows(uint8_t *buffer, int W, int H, int row0, int row1, int row_step, const Pose &pose, int threads) {
         Counters total;
+        (void)order();  // built here, before the threads start reading it
 #ifdef _OPENMP
         if (threads <= 0) threads = omp_get_max_threads();
 #pragma omp parallel num_threads(threads)
@@ -867,6 +888,7 @@ struct Engine {
                 Vec3 dir = pixel_direction(pose, W, H, x, y_inv);
                 Ray ray{camera_position, dir};
                 ray.smooth_k = smooth_k;
+        ray.order = order();
                 uint64_t h = ray.march(objects, NONE);
                 size_t i = (size_t)y_inv * W + x;
                 hit[i] = (h == NONE) ? -1 : (int32_t)h;
@@ -926,6 +948,7 @@ struct Engine {
                     vector_to_light = vector_to_light / distance_to_light;
                     Ray shadow_ray{origin, vector_to_light};
                     shadow_ray.smooth_k = smooth_k;
+                    shadow_ray.order = order();
                     (void)shadow_ray.march(objects, obj_index);
                     if ((shadow_ray.position - origin).mag() < (distance_to_light + 3.0f * SMALL_DISTANCE)) continue;
                     Vec3 nrm = object.calculate_normal(origin);
@@ -994,6 +1017,7 @@ struct Engine {
                     // `3.0 * SMALL_DISTANCE * -v` = (3.0*0.001) * (-v)
                     Ray shadow_ray{light_source + ((-vector_to_light) * (3.0f * SMALL_DISTANCE)), -vector_to_light};
                     shadow_ray.smooth_k = smooth_k;
+                    shadow_ray.order = order();
                     uint64_t hit = shadow_ray.march(objects, NONE, true);
                     if (hit != NONE) {
                         if (hit != obj_eng_index) {
@@ -1298,6 +1322,7 @@ void orc_kat_normal(void *h, int obj, const float *p, float *out) {
 int orc_kat_march(void *h, float *pos_io, const float *dir, int ignore, int radiosity) {
     Ray r{Vec3(pos_io[0], pos_io[1], pos_io[2]), Vec3(dir[0], dir[1], dir[2])};
     r.smooth_k = static_cast<Engine *>(h)->smooth_k;
+    r.order = static_cast<Engine *>(h)->order();
     uint64_t hit = r.march(static_cast<Engine *>(h)->objects, ignore < 0 ? NONE : (uint64_t)ignore, radiosity != 0);
     for (int i = 0; i < 3; i++) pos_io[i] = r.position.l[i];
     return hit == NONE ? -1 : (int)hit;
@@ -1305,6 +1330,7 @@ int orc_kat_march(void *h, float *pos_io, const float *dir, int ignore, int radi
 float orc_kat_shadow(void *h, const float *pos, const float *dir, int ignore, float light_dist, float k) {
     Ray r{Vec3(pos[0], pos[1], pos[2]), Vec3(dir[0], dir[1], dir[2])};
     r.smooth_k = static_cast<Engine *>(h)->smooth_k;
+    r.order = static_cast<Engine *>(h)->order();
     return r.smooth_shadow_march(static_cast<Engine *>(h)->objects, (uint64_t)ignore, light_dist, k);
 }
 void orc_kat_phong(const float *n, const float *l, float dist, float intensity, const float *mat, const float *view,

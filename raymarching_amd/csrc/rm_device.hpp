@@ -88,7 +88,10 @@ RM_DEV float sdf_eval(int type, const Geom &g, V3 p) {
 // Polynomial smooth minimum for "smooth unions" (an extension: the reference's union is the hard
 // minimum of ray.rs:23-33).
 RM_DEV float smooth_min(float a, float b, float k) {
-    float h = rs_max(k - fabsf(a - b), 0.0f) / k;
+    // |a - b| >= k makes h = 0 / k = 0 and the result min(a, b) - 0: no division needed then
+    const float gap = fabsf(a - b);
+    if (gap >= k) return rs_min(a, b);
+    float h = rs_max(k - gap, 0.0f) / k;
     return rs_min(a, b) - h * h * k * (1.0f / 4.0f);
 }
 
@@ -140,6 +143,10 @@ struct SceneSmallAcc {
         for (int i = 0; i < G::kPlanes; i++)
             if (G::kExact || i < g.n_gp) f(g.idx_gp[i], g.gp[i][0], g.gp[i][1], g.gp[i][2], g.gp[i][3]);
     }
+    template <class F>
+    RM_DEV void boxes(F &&) const {}  // scenes with boxes or smooth unions use the large layout
+    static constexpr bool kSmooth = false;
+    RM_DEV float smooth_k() const { return 0.0f; }
 };
 
 struct SceneLargeAcc {
@@ -159,6 +166,15 @@ struct SceneLargeAcc {
     RM_DEV void planes(F &&f) const {
         for (int i = 0; i < g.n_gp; i++) f(g.idx_gp[i], g.gp[4 * i], g.gp[4 * i + 1], g.gp[4 * i + 2], g.gp[4 * i + 3]);
     }
+    template <class F>
+    RM_DEV void boxes(F &&f) const {
+        for (int i = 0; i < g.n_box; i++) {
+            const float *b = g.box + 8 * i;
+            f(g.idx_box[i], v3(b[0], b[1], b[2]), v3(b[3], b[4], b[5]));
+        }
+    }
+    static constexpr bool kSmooth = true;
+    RM_DEV float smooth_k() const { return g.smooth_k; }
 };
 
 template <int NS, int NA, int NG, bool EX>
@@ -183,86 +199,73 @@ struct LaneIgnore {  // differs between lanes: evaluated, then masked
     RM_DEV float mask(int oi, float s) const { return oi == v ? __builtin_inff() : s; }
 };
 
-// min over objects of sdf(p): the value `distance` holds after the object loop
-// of ray.rs:23-33 / 98-107.
+// Box distance (extension, objects.rs:370-380 with centre c and half extents h).
+RM_DEV float box_sdf(V3 c, V3 h, V3 p) {
+    V3 q = v3(fabsf(p.x - c.x) - h.x, fabsf(p.y - c.y) - h.y, fabsf(p.z - c.z) - h.z);
+    V3 r = v3(rs_max(q.x, 0.0f), rs_max(q.y, 0.0f), rs_max(q.z, 0.0f));
+    return sqrt_rn(mag_sqd(r)) + rs_min(rs_max(q.x, rs_max(q.y, q.z)), 0.0f);
+}
+
+// The value `distance` holds after the object loop of ray.rs:23-33 / 98-107: the minimum over
+// objects of sdf(p) - or, with a smooth union (extension), their smooth-minimum fold in group
+// order.
 //
-// A sphere whose distance provably cannot be below the running minimum skips
-// its square root: with T >= d + r and m >= T*T (both rounded upwards), the
-// correctly rounded sqrt(m) is >= T and sqrt(m) - r rounds to a value >= d.
+// A sphere whose distance provably cannot change the running value d skips its square root:
+// with T >= (d + k) + r and m >= T*T (both rounded upwards, with room for the additions), the
+// correctly rounded sqrt(m) is >= T and s = sqrt(m) - r rounds to a value >= d + k, for which
+// min(d, s) = d and smooth_min(d, s, k) = d.
 //
-// `active` marks the lanes whose result is used: a finished lane must not keep
-// the rest of its wave on the square-root path.
+// `active` marks the lanes whose result is used: a finished lane must not keep the rest of its
+// wave on the square-root path.
 template <class SC, class IGN>
 RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, bool active = true) {
+    const float k = sc.smooth_k();
+    const bool blend = SC::kSmooth && k > 0.0f;  // wave-uniform
     float d = __builtin_inff();
+    auto fold = [&](float s) {
+        if (blend)
+            d = smooth_min(d, s, k);
+        else
+            d = rs_min(d, s);
+    };
     sc.template axis<0>([&](int oi, float off, float dir) {
-        if (!ign.skip(oi)) d = rs_min(d, ign.mask(oi, dir * (p.x - off)));
+        if (!ign.skip(oi)) fold(ign.mask(oi, dir * (p.x - off)));
     });
     sc.template axis<1>([&](int oi, float off, float dir) {
-        if (!ign.skip(oi)) d = rs_min(d, ign.mask(oi, dir * (p.y - off)));
+        if (!ign.skip(oi)) fold(ign.mask(oi, dir * (p.y - off)));
     });
     sc.template axis<2>([&](int oi, float off, float dir) {
-        if (!ign.skip(oi)) d = rs_min(d, ign.mask(oi, dir * (p.z - off)));
+        if (!ign.skip(oi)) fold(ign.mask(oi, dir * (p.z - off)));
     });
     sc.planes([&](int oi, float nx, float ny, float nz, float dist) {
-        if (!ign.skip(oi)) d = rs_min(d, ign.mask(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist));
+        if (!ign.skip(oi)) fold(ign.mask(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist));
     });
     sc.spheres([&](int oi, float cx, float cy, float cz, float r) {
         if (ign.skip(oi)) return;
         float m = mag_sqd(p - v3(cx, cy, cz));
-        float tu = (d + r) * 1.0000005f;
+        float tu = (SC::kSmooth ? (d + k) + r : d + r) * 1.000001f;
         float q = (tu * tu) * 1.0000005f;
         bool far = (tu > 1e-15f) && (m >= q);
-        if (!far && active) d = rs_min(d, ign.mask(oi, sqrt_rn(m) - r));
+        if (!far && active) fold(ign.mask(oi, sqrt_rn(m) - r));
+    });
+    sc.boxes([&](int oi, V3 c, V3 h) {
+        if (!ign.skip(oi)) fold(ign.mask(oi, box_sdf(c, h, p)));
     });
     return d;
 }
 
-// The same for a scene walked in object order (boxes, smooth unions).  With smooth_k > 0 the
-// distances are folded with smooth_min in index order, which is part of the result.
-struct SceneOrderedAcc {
-    const OrderedScene &g;
-};
-RM_DEV SceneOrderedAcc acc_of(const OrderedScene &g) { return SceneOrderedAcc{g}; }
-
-template <class IGN>
-RM_DEV float scene_min(const SceneOrderedAcc &sc, V3 p, const IGN &ign, bool active = true) {
-    (void)active;
-    const float k = sc.g.smooth_k;
-    float d = __builtin_inff();
-    for (int i = 0; i < sc.g.n; i++) {
-        if (ign.skip(i)) continue;
-        const float s = ign.mask(i, sdf_eval(sc.g.type[i], sc.g.geom[i], p));
-        if (k > 0.0f)
-            d = smooth_min(d, s, k);
-        else if (s < d)
-            d = s;
-    }
-    return d;
-}
-
-// The hit object: smallest own distance, lowest index on ties (with or without blending).
-template <class IGN>
-RM_DEV int closest_index(const SceneOrderedAcc &sc, V3 p, float, const IGN &ign) {
-    float best = __builtin_inff();
-    int idx = -1;
-    for (int i = 0; i < sc.g.n; i++) {
-        if (ign.skip(i)) continue;
-        const float s = ign.mask(i, sdf_eval(sc.g.type[i], sc.g.geom[i], p));
-        if (s < best) {
-            best = s;
-            idx = i;
-        }
-    }
-    return idx;
-}
-
-// Lowest object index whose sdf at p equals d (every object evaluated exactly).
+// The hit object: smallest own distance, lowest index on ties (the strict `<` of ray.rs:29);
+// every object is evaluated exactly here.
 template <class SC, class IGN>
-RM_DEV int closest_index(const SC &sc, V3 p, float d, const IGN &ign) {
-    int best = 0x7fffffff;
-    auto take = [&](int oi, float s) {
-        if (ign.mask(oi, s) == d && oi < best) best = oi;
+RM_DEV int closest_index(const SC &sc, V3 p, float, const IGN &ign) {
+    float best = __builtin_inff();
+    int bi = 0x7fffffff;
+    auto take = [&](int oi, float s0) {
+        const float s = ign.mask(oi, s0);
+        if (s < best || (s == best && oi < bi)) {
+            best = s;
+            bi = oi;
+        }
     };
     sc.template axis<0>([&](int oi, float off, float dir) {
         if (!ign.skip(oi)) take(oi, dir * (p.x - off));
@@ -279,7 +282,10 @@ RM_DEV int closest_index(const SC &sc, V3 p, float d, const IGN &ign) {
     sc.spheres([&](int oi, float cx, float cy, float cz, float r) {
         if (!ign.skip(oi)) take(oi, sqrt_rn(mag_sqd(p - v3(cx, cy, cz))) - r);
     });
-    return best == 0x7fffffff ? -1 : best;
+    sc.boxes([&](int oi, V3 c, V3 h) {
+        if (!ign.skip(oi)) take(oi, box_sdf(c, h, p));
+    });
+    return (bi == 0x7fffffff || !(best < __builtin_inff())) ? -1 : bi;
 }
 
 // ray.rs:15-42 (and ray.rs:58-85: every object type collides, objects.rs:220,343).

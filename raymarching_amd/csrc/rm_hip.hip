@@ -390,8 +390,7 @@ struct rm_engine {
 
     // device-resident scene
     int n = 0, n_lm = 0, n_patches = 0;
-    int tier = 2;  // -1: GroupedTierX, 0: GroupedTierA, 1: GroupedTierB, 2: GroupedLarge, 3: OrderedScene
-    OrderedScene ordered_scene;
+    int tier = 2;  // -1: GroupedTierX, 0: GroupedTierA, 1: GroupedTierB, 2: GroupedLarge
     GroupedTierX tier_x;
     GroupedTierA tier_a;
     GroupedTierB tier_b;
@@ -503,9 +502,8 @@ static int engine_upload(rm_engine *e) {
     e->lm_slot.assign(e->n, -1);
     e->patch_obj.clear();
     // objects grouped by type for the march loops (original indices kept alongside)
-    std::vector<int> gi_sph, gi_ax[3], gi_gp;
-    std::vector<float> g_sph, g_ax[3], g_gp;
-    int n_boxes = 0;
+    std::vector<int> gi_sph, gi_ax[3], gi_gp, gi_box;
+    std::vector<float> g_sph, g_ax[3], g_gp, g_box;
     for (int i = 0; i < e->n; i++) {
         const HostObject &o = s.objects[i];
         type[i] = o.type;
@@ -550,10 +548,12 @@ static int engine_upload(rm_engine *e) {
                 g_gp.insert(g_gp.end(), o.p, o.p + 4);
                 break;
             default:
-                n_boxes++;
+                gi_box.push_back(i);
+                g_box.insert(g_box.end(), o.p, o.p + 8);
                 break;
         }
     }
+    const int n_boxes = (int)gi_box.size();
     auto fits = [&](int ns, int na, int ng) {
         return (int)gi_sph.size() <= ns && (int)gi_ax[0].size() <= na && (int)gi_ax[1].size() <= na &&
                (int)gi_ax[2].size() <= na && (int)gi_gp.size() <= ng;
@@ -583,7 +583,7 @@ static int engine_upload(rm_engine *e) {
     memset(&e->tier_b, 0, sizeof(e->tier_b));
     memset(&e->tier_x, 0, sizeof(e->tier_x));
     if (n_boxes > 0 || s.smooth_k > 0.0f) {
-        e->tier = 3;  // evaluation order matters or the scene holds boxes: ordered walk
+        e->tier = 2;  // boxes and smooth unions live in the large layout only
     } else if (gi_sph.size() == 2 && gi_ax[0].size() == 2 && gi_ax[1].size() == 2 && gi_ax[2].size() == 2 && gi_gp.empty()) {
         e->tier = -1;
         fill(e->tier_x);
@@ -604,6 +604,8 @@ static int engine_upload(rm_engine *e) {
         gl.n_y = (int)gi_ax[1].size();
         gl.n_z = (int)gi_ax[2].size();
         gl.n_gp = (int)gi_gp.size();
+        gl.n_box = n_boxes;
+        gl.smooth_k = s.smooth_k;
         auto up_i = [&](const std::vector<int> &v, const int **dst) -> hipError_t {
             int *d = nullptr;
             hipError_t err = dev_alloc(&d, v.size());
@@ -628,17 +630,19 @@ static int engine_upload(rm_engine *e) {
         }
         HIP_TRY(up_i(gi_gp, &gl.idx_gp));
         HIP_TRY(up_f(g_gp, &gl.gp));
+        HIP_TRY(up_i(gi_box, &gl.idx_box));
+        HIP_TRY(up_f(g_box, &gl.box));
     }
     e->n_lm = (int)e->patch_obj.size();
     e->n_patches = e->n_lm * e->M * e->M;
 
-    HIP_TRY(dev_alloc(&e->d_type, e->n));
-    HIP_TRY(dev_alloc(&e->d_geom, e->n));
+    const int n_pad = e->n;
+    HIP_TRY(dev_alloc(&e->d_type, n_pad));
+    HIP_TRY(dev_alloc(&e->d_geom, n_pad));
     HIP_TRY(dev_alloc(&e->d_shade, e->n));
-    HIP_TRY(hipMemcpy(e->d_type, type.data(), sizeof(int) * e->n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_geom, geom.data(), sizeof(Geom) * e->n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_type, type.data(), sizeof(int) * n_pad, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_geom, geom.data(), sizeof(Geom) * n_pad, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_shade, shade.data(), sizeof(ShadeRec) * e->n, hipMemcpyHostToDevice));
-    e->ordered_scene = OrderedScene{e->n, e->d_type, e->d_geom, s.smooth_k};
 
     std::vector<TextureRec> tex(s.textures.size());
     e->d_texels.assign(s.textures.size(), nullptr);
@@ -695,9 +699,6 @@ static void engine_free(rm_engine *e) {
             hipLaunchKernelGGL((KERNEL<GroupedTierA>), grid, block, 0, (e)->stream, __VA_ARGS__, (e)->tier_a); \
         else if ((e)->tier == 1)                                                                              \
             hipLaunchKernelGGL((KERNEL<GroupedTierB>), grid, block, 0, (e)->stream, __VA_ARGS__, (e)->tier_b); \
-        else if ((e)->tier == 3)                                                                              \
-            hipLaunchKernelGGL((KERNEL<OrderedScene>), grid, block, 0, (e)->stream, __VA_ARGS__,              \
-                               (e)->ordered_scene);                                                           \
         else                                                                                                  \
             hipLaunchKernelGGL((KERNEL<GroupedLarge>), grid, block, 0, (e)->stream, __VA_ARGS__,              \
                                (e)->large_scene);                                                             \

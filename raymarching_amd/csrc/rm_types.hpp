@@ -73,23 +73,20 @@ typedef GroupedSmall<2, 2, 0> GroupedTierA;
 typedef GroupedSmall<4, 4, 2> GroupedTierB;
 
 struct GroupedLarge {
-    int n_sph, n_x, n_y, n_z, n_gp;
+    int n_sph, n_x, n_y, n_z, n_gp, n_box;
     const int *idx_sph;  // original object index of each entry
     const int *idx_ax[3];
     const int *idx_gp;
-    const float *sph;  // [n_sph][4]
+    const int *idx_box;
+    const float *sph;    // [n_sph][4]
     const float *ax[3];  // [n][2]
     const float *gp;     // [n_gp][4]
-};
-
-// A scene walked in object order with a per-object type switch: the path for scenes that hold
-// boxes or blend distances with a smooth minimum (both extensions of the reference's object set),
-// where the order of evaluation is part of the result.
-struct OrderedScene {
-    int n;
-    const int *type;   // [n]
-    const Geom *geom;  // [n]
-    float smooth_k;    // 0 = hard minimum
+    const float *box;    // [n_box][8]: cx, cy, cz, hx, hy, hz, -, -
+    // Extension: > 0 folds the distances with a smooth minimum instead of the hard one.  The fold
+    // runs in the order of the groups (X, Y, Z planes, generic planes, spheres, boxes; by object
+    // index within a group), which is part of the definition since the smooth minimum does not
+    // associate.
+    float smooth_k;
 };
 
 struct SceneView {
