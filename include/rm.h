@@ -168,6 +168,17 @@ int rm_engine_set_camera(rm_engine *engine, const float position[3]);
 int rm_engine_render(rm_engine *engine, uint8_t *bgra, size_t pitch_bytes, int32_t mouse_x, int32_t mouse_y,
                      const float rel_move[3], int32_t scroll);
 
+/* Engine::render for a frame loop (main.rs:82-151) without a stall per frame: the input
+ * block is applied at once, the frame and its copy into `bgra` are enqueued, and the call
+ * returns.  `bgra` must be page-locked (rm_host_alloc).  Up to RM_FRAMES_IN_FLIGHT frames
+ * may be pending: the copy of frame f runs on a second stream while frame f+1 renders.
+ * rm_engine_render_wait blocks until the oldest pending frame has landed in its buffer;
+ * rm_engine_render_async waits by itself when every slot is taken. */
+#define RM_FRAMES_IN_FLIGHT 2
+int rm_engine_render_async(rm_engine *engine, uint8_t *bgra, size_t pitch_bytes, int32_t mouse_x, int32_t mouse_y,
+                           const float rel_move[3], int32_t scroll);
+int rm_engine_render_wait(rm_engine *engine);
+
 /* Passes 1-3 of Engine::render (engine.rs:77-126) for image rows
  * [row_begin,row_end) at the pose of the last rm_engine_input, written to device
  * memory; `d_bgra` points at the first byte of row `row_begin`.  Asynchronous on

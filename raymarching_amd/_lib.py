@@ -53,6 +53,8 @@ SIGNATURES = {
     "rm_engine_get_camera": (c_int, [c_void_p, _F3]),
     "rm_engine_set_camera": (c_int, [c_void_p, _F3]),
     "rm_engine_render": (c_int, [c_void_p, POINTER(c_uint8), c_size_t, c_int32, c_int32, _F3, c_int32]),
+    "rm_engine_render_async": (c_int, [c_void_p, c_void_p, c_size_t, c_int32, c_int32, _F3, c_int32]),
+    "rm_engine_render_wait": (c_int, [c_void_p]),
     "rm_engine_render_rows_device": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int]),
     "rm_engine_render_strips_device": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int]),
     "rm_engine_fxaa_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),

@@ -411,6 +411,15 @@ struct rm_engine {
     unsigned char *d_frame = nullptr;  // W*H*4, for rm_engine_render
     unsigned char *h_stage = nullptr;  // pinned W*H*4 staging for callers that pass pageable memory
 
+    // frames in flight for rm_engine_render_async: render on `stream`, copy out on `copy_stream`
+    unsigned char *d_async[RM_FRAMES_IN_FLIGHT] = {};
+    hipEvent_t ev_rendered[RM_FRAMES_IN_FLIGHT] = {};
+    hipEvent_t ev_copied[RM_FRAMES_IN_FLIGHT] = {};
+    bool async_pending[RM_FRAMES_IN_FLIGHT] = {};
+    hipStream_t copy_stream = nullptr;
+    int async_head = 0;  // slot the next frame goes to
+    int async_tail = 0;  // oldest pending slot
+
     // radiosity work buffers
     int *d_patch_obj = nullptr;
     float *d_pos = nullptr, *d_col = nullptr, *d_nrm = nullptr;
@@ -680,6 +689,12 @@ static void engine_free(rm_engine *e) {
     (void)hipFree(e->d_view);
     (void)hipFree(e->d_frame);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
+    for (int i = 0; i < RM_FRAMES_IN_FLIGHT; i++) {
+        (void)hipFree(e->d_async[i]);
+        if (e->ev_rendered[i]) (void)hipEventDestroy(e->ev_rendered[i]);
+        if (e->ev_copied[i]) (void)hipEventDestroy(e->ev_copied[i]);
+    }
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     (void)hipFree(e->d_patch_obj);
     (void)hipFree(e->d_pos);
     (void)hipFree(e->d_col);
@@ -986,6 +1001,52 @@ int rm_engine_render(rm_engine *e, uint8_t *bgra, size_t pitch_bytes, int32_t mo
     } else {
         for (int y = 0; y < e->H; y++) memcpy(bgra + (size_t)y * pitch_bytes, e->h_stage + (size_t)y * e->W * 4, (size_t)e->W * 4);
     }
+    return RM_OK;
+}
+
+int rm_engine_render_wait(rm_engine *e) {
+    if (!e) return fail(RM_ERR_INVALID, "NULL engine");
+    const int slot = e->async_tail;
+    if (!e->async_pending[slot]) return fail(RM_ERR_INVALID, "no frame is pending");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(e->ev_copied[slot]));
+    e->async_pending[slot] = false;
+    e->async_tail = (slot + 1) % RM_FRAMES_IN_FLIGHT;
+    return RM_OK;
+}
+
+int rm_engine_render_async(rm_engine *e, uint8_t *bgra, size_t pitch_bytes, int32_t mouse_x, int32_t mouse_y,
+                           const float rel_move[3], int32_t scroll) {
+    if (!e || !bgra) return fail(RM_ERR_INVALID, "NULL argument");
+    if (pitch_bytes < (size_t)e->W * 4) return fail(RM_ERR_INVALID, "pitch must be >= width*4");
+    HIP_TRY(hipSetDevice(e->device));
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, bgra) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    if (!pinned) return fail(RM_ERR_INVALID, "rm_engine_render_async needs a page-locked destination (rm_host_alloc)");
+    const int slot = e->async_head;
+    if (e->async_pending[slot]) {  // every slot is in use: the oldest frame has to land first
+        int rc = rm_engine_render_wait(e);
+        if (rc) return rc;
+    }
+    if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    if (!e->d_async[slot]) {
+        HIP_TRY(dev_alloc(&e->d_async[slot], (size_t)e->W * e->H * 4));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_rendered[slot], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_copied[slot], hipEventDisableTiming));
+    }
+    int rc = rm_engine_input(e, mouse_x, mouse_y, rel_move, scroll);
+    if (rc) return rc;
+    // the previous copy out of this slot has finished (its frame was waited for), so it can be overwritten
+    rc = rm_engine_render_rows_device(e, e->d_async[slot], (size_t)e->W * 4, 0, e->H);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e->ev_rendered[slot], e->stream));
+    HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_rendered[slot], 0));
+    HIP_TRY(hipMemcpy2DAsync(bgra, pitch_bytes, e->d_async[slot], (size_t)e->W * 4, (size_t)e->W * 4, e->H,
+                             hipMemcpyDeviceToHost, e->copy_stream));
+    HIP_TRY(hipEventRecord(e->ev_copied[slot], e->copy_stream));
+    e->async_pending[slot] = true;
+    e->async_head = (slot + 1) % RM_FRAMES_IN_FLIGHT;
     return RM_OK;
 }
 

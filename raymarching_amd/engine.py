@@ -162,6 +162,18 @@ class Engine:
         )
         return buffer
 
+    def render_async(self, host_ptr: int, mouse_x=0, mouse_y=0, rel_move=(0.0, 0.0, 0.0), scroll=0, pitch=None):
+        """Enqueue a frame and its copy into page-locked memory at host_ptr (rm_host_alloc); returns at once."""
+        pitch = self.width * 4 if pitch is None else pitch
+        _lib.check(
+            self.lib.rm_engine_render_async(self.handle, c_void_p(host_ptr), pitch, mouse_x, mouse_y, _lib.f3(rel_move), scroll),
+            "rm_engine_render_async",
+        )
+
+    def render_wait(self):
+        """Block until the oldest pending render_async frame has landed in its buffer."""
+        _lib.check(self.lib.rm_engine_render_wait(self.handle), "rm_engine_render_wait")
+
     def render_rows_device(self, d_ptr: int, row_begin: int, row_end: int, pitch=None):
         """Rows [row_begin,row_end) at the current pose into device memory at d_ptr (async)."""
         pitch = self.width * 4 if pitch is None else pitch

@@ -41,4 +41,21 @@ t.sort()
 med = t[len(t) // 2]
 print(f"rm_engine_render 4K into rm_host_alloc memory: median {med*1e3:.3f} ms -> {W*H/med/1e6:.0f} Mrays/s")
 assert np.array_equal(pinned, buf)
+
+# pipelined: the copy of frame f overlaps the render of frame f+1
+ptr2 = lib.rm_host_alloc(W * H * 4)
+ptrs = [ptr, ptr2]
+N = 60
+for f in range(4):
+    eng.render_async(ptrs[f & 1])
+for _ in range(2):
+    eng.render_wait()
+t0 = time.perf_counter()
+for f in range(N):
+    eng.render_async(ptrs[f & 1])
+eng.render_wait()
+eng.render_wait()
+dt = (time.perf_counter() - t0) / N
+print(f"rm_engine_render_async 4K, two frames in flight: {dt*1e3:.3f} ms per frame -> {W*H/dt/1e6:.0f} Mrays/s")
 lib.rm_host_free(ptr)
+lib.rm_host_free(ptr2)
