@@ -15,10 +15,60 @@ namespace rm {
 #define RM_DEV __device__ __forceinline__
 
 // Diagnostic builds (-DRM_ABL=bits) switch parts of the pixel path off to time the rest:
-// 1 soft shadow, 2 reflections, 4 lightmap sampling, 8 everything after the primary march.
+// 1 soft shadow, 2 reflections, 4 lightmap sampling, 8 everything after the primary march,
+// 16 tone mapping, 32 surface normal, 64 object colour, 128 Phong terms.
 // The shipped library is built with 0.
 #ifndef RM_ABL
 #define RM_ABL 0
+#endif
+
+// Diagnostic builds (-DRM_DIAG) count march-loop iterations per wave and per lane in LDS; the
+// render kernel adds them to the spare statistics slots 4..6.
+#ifdef RM_DIAG
+RM_DEV unsigned *diag_mem() {
+    __shared__ unsigned m[65];
+    return m;
+}
+RM_DEV unsigned *diag_kinds() {
+    __shared__ unsigned kinds[8];
+    return kinds;
+}
+RM_DEV void diag_iter(bool active, int kind = 0) {
+    unsigned *m = diag_mem();
+    m[threadIdx.x] += active ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        m[64] += 1u;
+        diag_kinds()[kind] += 1u;
+    }
+}
+RM_DEV void diag_event(int kind) {  // once per wave however many lanes get here
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) == threadIdx.x) diag_kinds()[kind] += 1u;
+}
+// The cycles since the previous lap go to section k.
+enum { DG_SETUP = 0, DG_MARCH_LOOP, DG_CLOSEST, DG_SHADE, DG_SHADOW, DG_REFLECT, DG_PACK, DG_SECTIONS };
+RM_DEV unsigned *diag_laps() {
+    __shared__ unsigned t[2 + DG_SECTIONS];
+    return t;
+}
+RM_DEV void diag_lap(int k) {
+    unsigned *t = diag_laps();
+    const unsigned now = (unsigned)__builtin_readcyclecounter();
+    if (threadIdx.x == 0) {
+        t[2 + k] += now - t[0];
+        t[0] = (unsigned)__builtin_readcyclecounter();
+    }
+}
+#else
+RM_DEV void diag_iter(bool, int = 0) {}
+RM_DEV void diag_event(int) {}
+RM_DEV void diag_lap(int) {}
+#define DG_SETUP 0
+#define DG_MARCH_LOOP 0
+#define DG_CLOSEST 0
+#define DG_SHADE 0
+#define DG_SHADOW 0
+#define DG_REFLECT 0
+#define DG_PACK 0
 #endif
 
 struct V3 {
@@ -128,7 +178,7 @@ struct SceneSmallAcc {
     RM_DEV void spheres(F &&f) const {
 #pragma unroll
         for (int i = 0; i < G::kSpheres; i++)
-            if (G::kExact || i < g.n_sph) f(g.idx_sph[i], g.sph[i][0], g.sph[i][1], g.sph[i][2], g.sph[i][3]);
+            if (G::kExact || i < g.n_sph) f(i, g.idx_sph[i], g.sph[i][0], g.sph[i][1], g.sph[i][2], g.sph[i][3]);
     }
     template <int AXIS, class F>
     RM_DEV void axis(F &&f) const {
@@ -146,6 +196,8 @@ struct SceneSmallAcc {
     template <class F>
     RM_DEV void boxes(F &&) const {}  // scenes with boxes or smooth unions use the large layout
     static constexpr bool kSmooth = false;
+    RM_DEV float sphere_extent() const { return g.sph_extent; }
+    static constexpr bool kUnitAxis = G::kExact;  // the exact-fill tier also promises |dir| = 1 on every axis plane
     RM_DEV float smooth_k() const { return 0.0f; }
 };
 
@@ -153,7 +205,7 @@ struct SceneLargeAcc {
     const GroupedLarge &g;
     template <class F>
     RM_DEV void spheres(F &&f) const {
-        for (int i = 0; i < g.n_sph; i++) f(g.idx_sph[i], g.sph[4 * i], g.sph[4 * i + 1], g.sph[4 * i + 2], g.sph[4 * i + 3]);
+        for (int i = 0; i < g.n_sph; i++) f(i, g.idx_sph[i], g.sph[4 * i], g.sph[4 * i + 1], g.sph[4 * i + 2], g.sph[4 * i + 3]);
     }
     template <int AXIS, class F>
     RM_DEV void axis(F &&f) const {
@@ -174,6 +226,8 @@ struct SceneLargeAcc {
         }
     }
     static constexpr bool kSmooth = true;
+    RM_DEV float sphere_extent() const { return g.sph_extent; }
+    static constexpr bool kUnitAxis = false;
     RM_DEV float smooth_k() const { return g.smooth_k; }
 };
 
@@ -199,6 +253,49 @@ struct LaneIgnore {  // differs between lanes: evaluated, then masked
     RM_DEV float mask(int oi, float s) const { return oi == v ? __builtin_inff() : s; }
 };
 
+// A lower bound on the distance to the nearest sphere, carried along one march.
+//
+// Distances are 1-Lipschitz: after moving a path of length L, every sphere is still at least
+// S - L away, S being the smallest sphere distance where it was last evaluated.  While the running
+// minimum d over the other objects stays below that, no sphere can change it and the whole group
+// is left out of the step.  With t the distance travelled as the march itself sums it, the group
+// is skipped while
+//
+//     d + t * dn  <=  T,      T = (S - M) + t_e * dn    (fixed at the evaluation, t_e = t there)
+//
+// dn bounds the path length per unit of t, roundings included.  Every step that is followed by
+// another evaluation is at least SMALL_DISTANCE long, so per-step errors are at most 1e3 times
+// the step: with P >= every |coordinate| reached,
+//   * the step vector dir*d is at most 1.00001 |dir| d long;
+//   * a position update leaves the ideal segment by at most 3.1e-7 P        <= 3.1e-4 P d;
+//   * an addition to t rounds by at most 2^-24 * 64                         <= 3.8e-3 d,
+// so L <= (t - t_e) * 1.004 * (1.00001 |dir| + 3.1e-4 P) <= (t - t_e) * dn with
+// dn = 1.0041 |dir| + 3.2e-4 P.  M takes the errors that do not grow with the path: two computed
+// sphere distances, each within 1.1e-6 (P + C) of the true one (C the largest |centre coordinate|
+// + radius; this includes the one-ulp square root the bound is built from), and the two fused
+// multiply-adds above, 4e-6 dn each: M = 1e-5 (P + C) + 1e-4 (1 + dn).
+// A NaN anywhere makes the comparison fail, which means "evaluate".
+struct SphereBound {
+    float T;    // per lane
+    float dn;   // per ray
+    float M;
+    float eps;  // 2e-6 (P + C): more than any sphere distance differs from its one-ulp estimate
+};
+
+template <class SC>
+RM_DEV SphereBound make_bound(const SC &sc, V3 o, V3 dir, float tmax) {
+    SphereBound b;
+    b.T = -__builtin_inff();
+    const float amax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+    const float dmax = fmaxf(fmaxf(fabsf(dir.x), fabsf(dir.y)), fabsf(dir.z));
+    const float P = (amax + tmax * dmax) * 1.001f + 1.0f;
+    const float dd = (dir.x * dir.x + dir.y * dir.y) + dir.z * dir.z;
+    b.dn = __builtin_amdgcn_sqrtf(dd) * 1.0041f + 3.2e-4f * P;
+    b.M = 1e-5f * (P + sc.sphere_extent()) + 1e-4f * (1.0f + b.dn);
+    b.eps = 2e-6f * (P + sc.sphere_extent());
+    return b;
+}
+
 // Box distance (extension, objects.rs:370-380 with centre c and half extents h).
 RM_DEV float box_sdf(V3 c, V3 h, V3 p) {
     V3 q = v3(fabsf(p.x - c.x) - h.x, fabsf(p.y - c.y) - h.y, fabsf(p.z - c.z) - h.z);
@@ -210,15 +307,10 @@ RM_DEV float box_sdf(V3 c, V3 h, V3 p) {
 // objects of sdf(p) - or, with a smooth union (extension), their smooth-minimum fold in group
 // order.
 //
-// A sphere whose distance provably cannot change the running value d skips its square root:
-// with T >= (d + k) + r and m >= T*T (both rounded upwards, with room for the additions), the
-// correctly rounded sqrt(m) is >= T and s = sqrt(m) - r rounds to a value >= d + k, for which
-// min(d, s) = d and smooth_min(d, s, k) = d.
-//
-// `active` marks the lanes whose result is used: a finished lane must not keep the rest of its
-// wave on the square-root path.
+// `active` marks the lanes whose result is used: a finished lane must not pull the rest of its
+// wave into the sphere evaluation.
 template <class SC, class IGN>
-RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, bool active = true) {
+RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, bool active, SphereBound &sb, float travelled) {
     const float k = sc.smooth_k();
     const bool blend = SC::kSmooth && k > 0.0f;  // wave-uniform
     float d = __builtin_inff();
@@ -228,26 +320,47 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, bool active = true) {
         else
             d = rs_min(d, s);
     };
+    // objects.rs:275,295,315: dir * (p - off).  With dir = +-1 the product is exact, so the value is
+    // the rounded +-(p - off), which one fused multiply-add of (dir, p, -dir*off) also delivers:
+    // its addend is exact and loop-invariant.  (Only the sign of a zero result can differ, and the
+    // value feeds nothing but minimum and comparisons.)
+    auto axis_sdf = [&](float pc, float off, float dir) {
+        if constexpr (SC::kUnitAxis)
+            return __builtin_fmaf(dir, pc, -(dir * off));
+        else
+            return dir * (pc - off);
+    };
     sc.template axis<0>([&](int oi, float off, float dir) {
-        if (!ign.skip(oi)) fold(ign.mask(oi, dir * (p.x - off)));
+        if (!ign.skip(oi)) fold(ign.mask(oi, axis_sdf(p.x, off, dir)));
     });
     sc.template axis<1>([&](int oi, float off, float dir) {
-        if (!ign.skip(oi)) fold(ign.mask(oi, dir * (p.y - off)));
+        if (!ign.skip(oi)) fold(ign.mask(oi, axis_sdf(p.y, off, dir)));
     });
     sc.template axis<2>([&](int oi, float off, float dir) {
-        if (!ign.skip(oi)) fold(ign.mask(oi, dir * (p.z - off)));
+        if (!ign.skip(oi)) fold(ign.mask(oi, axis_sdf(p.z, off, dir)));
     });
     sc.planes([&](int oi, float nx, float ny, float nz, float dist) {
         if (!ign.skip(oi)) fold(ign.mask(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist));
     });
-    sc.spheres([&](int oi, float cx, float cy, float cz, float r) {
-        if (ign.skip(oi)) return;
-        float m = mag_sqd(p - v3(cx, cy, cz));
-        float tu = (SC::kSmooth ? (d + k) + r : d + r) * 1.000001f;
-        float q = (tu * tu) * 1.0000005f;
-        bool far = (tu > 1e-15f) && (m >= q);
-        if (!far && active) fold(ign.mask(oi, sqrt_rn(m) - r));
-    });
+    // spheres: the whole group is skipped while the carried bound proves it irrelevant (with a
+    // smooth union a sphere matters only within k of the running value)
+    const float reach = __builtin_fmaf(travelled, sb.dn, blend ? d + k : d);
+    if (active && !(reach <= sb.T)) {
+        diag_event(3);
+        // The bound only needs each distance to within a few ulp: the hardware square root (one
+        // ulp) serves.  The correctly rounded value is computed only for a sphere that comes
+        // within sb.eps of deciding the result; eps exceeds the gap between the two values.
+        const float decide = (blend ? d + k : d) + sb.eps;
+        float nearest = __builtin_inff();
+        sc.spheres([&](int, int oi, float cx, float cy, float cz, float r) {
+            if (ign.skip(oi)) return;
+            const float m = mag_sqd(p - v3(cx, cy, cz));
+            const float rough = ign.mask(oi, __builtin_amdgcn_sqrtf(m) - r);
+            nearest = rs_min(nearest, rough);
+            if (!(rough > decide)) fold(ign.mask(oi, sqrt_rn(m) - r));
+        });
+        sb.T = __builtin_fmaf(travelled, sb.dn, nearest - sb.M);
+    }
     sc.boxes([&](int oi, V3 c, V3 h) {
         if (!ign.skip(oi)) fold(ign.mask(oi, box_sdf(c, h, p)));
     });
@@ -279,7 +392,7 @@ RM_DEV int closest_index(const SC &sc, V3 p, float, const IGN &ign) {
     sc.planes([&](int oi, float nx, float ny, float nz, float dist) {
         if (!ign.skip(oi)) take(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist);
     });
-    sc.spheres([&](int oi, float cx, float cy, float cz, float r) {
+    sc.spheres([&](int, int oi, float cx, float cy, float cz, float r) {
         if (!ign.skip(oi)) take(oi, sqrt_rn(mag_sqd(p - v3(cx, cy, cz))) - r);
     });
     sc.boxes([&](int oi, V3 c, V3 h) {
@@ -297,13 +410,14 @@ RM_DEV int march_capped(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, 
     bool hit = false;
     steps = 0;
     capped = false;
+    SphereBound sb = make_bound(sc, pos, dir, MAX_MARCH_DISTANCE);
     while (travelled < MAX_MARCH_DISTANCE) {
         if (steps >= cap) {
             capped = true;
             return -1;
         }
         steps++;
-        d = scene_min(sc, pos, ign);
+        d = scene_min(sc, pos, ign, true, sb, travelled);
         if (d < SMALL_DISTANCE) {
             hit = true;
             break;
@@ -326,8 +440,10 @@ RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, in
     float d_hit = 0.0f;
     bool hit = false;
     bool active = true;  // travelled = 0 < MAX_MARCH_DISTANCE
+    SphereBound sb = make_bound(sc, pos, dir, MAX_MARCH_DISTANCE);
     do {
-        const float d = scene_min(sc, pos, ign, active);
+        diag_iter(active, 1);
+        const float d = scene_min(sc, pos, ign, active, sb, travelled);
         const bool near = d < SMALL_DISTANCE;
         const bool hit_now = active && near;
         const bool go = active && !near;
@@ -342,7 +458,10 @@ RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, in
         pos.z = go ? p2.z : pos.z;
         active = go && (t2 < MAX_MARCH_DISTANCE);
     } while (__any(active));
-    return hit ? closest_index(sc, pos, d_hit, ign) : -1;
+    diag_lap(DG_MARCH_LOOP);
+    const int idx = hit ? closest_index(sc, pos, d_hit, ign) : -1;
+    diag_lap(DG_CLOSEST);
+    return idx;
 }
 
 // `ignore` < 0 means None.  A wave whose lanes all leave out the same object
@@ -364,8 +483,10 @@ RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float lig
     float travelled = 0.0f;
     float shade = 1.0f;
     bool active = true;
+    SphereBound sb = make_bound(sc, pos, dir, light_dist);
     for (int it = 0; it < MAX_SHAD_IT; it++) {
-        const float d = scene_min(sc, pos, ign, active);
+        diag_iter(active, 2);
+        const float d = scene_min(sc, pos, ign, active, sb, travelled);
         // shade = min(shade, smoothstep(clamp(k*d / travelled, 0, 1))).  With a = k*d >= travelled
         // >= 0 the correctly rounded quotient is >= 1 (or +inf, or NaN for 0/0): the clamp gives 1
         // (or keeps the NaN), smoothstep(1) = 1, and min(shade, 1 or NaN) leaves shade (<= 1) as it
@@ -373,6 +494,7 @@ RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float lig
         const float a = k * d;
         float sh2 = shade;
         if (!(a >= travelled && travelled >= 0.0f) && active) {
+            diag_event(4);
             const float x = rs_clamp(a / travelled, 0.0f, 1.0f);
             const float ss = 3.0f * (x * x) - 2.0f * (x * (x * x));
             sh2 = rs_min(shade, ss);
@@ -575,8 +697,8 @@ RM_DEV ShadeResult shade_local(const SC &sc, const SceneView &sv, int idx, V3 po
     const ShadeRec sr = sv.shade[idx];
     const Geom g = sv.geom[idx];
     ShadeResult out;
-    V3 oc = object_colour(sv, sr, g, pos);
-    V3 n = calculate_normal(sr.type, g, pos);
+    V3 oc = (RM_ABL & 64) ? v3(sr.cr, sr.cg, sr.cb) : object_colour(sv, sr, g, pos);
+    V3 n = (RM_ABL & 32) ? v3(0.0f, 1.0f, 0.0f) : calculate_normal(sr.type, g, pos);
 
     V3 ambient;
     if ((RM_ABL & 4) || sr.lm_slot < 0)
@@ -591,10 +713,12 @@ RM_DEV ShadeResult shade_local(const SC &sc, const SceneView &sv, int idx, V3 po
     float dist = mag(to_light);
     to_light = to_light / dist;
 
-    float diffuse, specular;
-    phong_ds(n, to_light, dist, sv.intensity, sr, dir, diffuse, specular);
+    float diffuse = 0.5f, specular = 0.0f;
+    if (!(RM_ABL & 128)) phong_ds(n, to_light, dist, sv.intensity, sr, dir, diffuse, specular);
+    diag_lap(DG_SHADE);
     float shade = (RM_ABL & 1) ? 1.0f : smooth_shadow_march(sc, pos, to_light, idx, dist, SHADOW_K);
 
+    diag_lap(DG_SHADOW);
     out.final_colour = ambient + oc * (shade * (diffuse + specular));
     out.object_colour = oc;
     out.n = n;
@@ -612,6 +736,8 @@ RM_DEV V3 cast_sight_ray(const SC &sc, const SceneView &sv, V3 pos, V3 dir) {
     for (;;) {
         int steps;
         bool capped;
+        diag_lap(DG_REFLECT);
+        diag_event(5);
         int idx = march(sc, pos, dir, -1, sv.march_cap, steps, capped);
         if (capped) atomicAdd(&sv.stats[1], 1ULL);
         if (idx < 0) {
@@ -687,6 +813,7 @@ RM_DEV unsigned to_pixel_range(float i) {
 // engine.rs:109-125 for one pixel: linear colour -> packed B,G,R,0 bytes
 RM_DEV unsigned pack_pixel(V3 linear, float exposure) {
     V3 c = linear * exposure;
+    if (RM_ABL & 16) return to_pixel_range(c.x) | (to_pixel_range(c.y) << 8) | (to_pixel_range(c.z) << 16);
     float r = sqrtf(aces(c.x)), g = sqrtf(aces(c.y)), b = sqrtf(aces(c.z));
     return to_pixel_range(b) | (to_pixel_range(g) << 8) | (to_pixel_range(r) << 16);
 }

@@ -58,13 +58,68 @@ __device__ __forceinline__ void tile_pixel(const RenderArgs &a, int &x, int &y_i
 template <class G>
 __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderArgs a, const G g) {
     int x, y_inv, out_row;
+#ifdef RM_DIAG_TIME
+    const unsigned long long diag_t0 = wall_clock64();
+#endif
     tile_pixel(a, x, y_inv, out_row);
+#ifdef RM_DIAG
+    diag_mem()[threadIdx.x] = 0;
+    if (threadIdx.x == 0) diag_mem()[64] = 0;
+    if (threadIdx.x < 2 + DG_SECTIONS) diag_laps()[threadIdx.x] = 0;
+    if (threadIdx.x < 8) diag_kinds()[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) diag_laps()[0] = (unsigned)__builtin_readcyclecounter();
+    const unsigned long long wave_t0 = wall_clock64();  // 100 MHz
+#endif
     if (x >= a.pose.W || y_inv >= a.row_end) return;
     V3 dir = pixel_direction(a.pose, x, y_inv);
     V3 cam = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
+    diag_lap(DG_SETUP);
     V3 colour = cast_sight_ray(acc_of(g), *a.sv, cam, dir);
+    diag_lap(DG_REFLECT);
+#ifdef RM_DIAG
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned mx = 0, sum = 0;
+        for (int i = 0; i < 64; i++) {
+            mx = max(mx, diag_mem()[i]);
+            sum += diag_mem()[i];
+        }
+        atomicAdd(&a.sv->stats[4], (unsigned long long)diag_mem()[64]);  // loop iterations the wave ran
+        atomicAdd(&a.sv->stats[5], (unsigned long long)mx);              // iterations of its busiest lane
+        atomicAdd(&a.sv->stats[6], (unsigned long long)sum);             // lane iterations in use
+    }
+#endif
     unsigned px = pack_pixel(colour, a.pose.exposure);
+#ifdef RM_DIAG_TIME
+    // the first three pixels of each tile carry the wave's start, end (10 ns ticks, low 32 bits)
+    // and the compute unit it ran on, instead of colours
+    {
+        const unsigned long long t1 = wall_clock64();
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if (threadIdx.x == 0) px = (unsigned)diag_t0;
+        if (threadIdx.x == 1) px = (unsigned)t1;
+        if (threadIdx.x == 2) px = hw;
+    }
+#endif
     *reinterpret_cast<unsigned *>(a.out + (size_t)out_row * a.pitch + (size_t)x * 4) = px;
+#ifdef RM_DIAG
+    diag_lap(DG_PACK);
+    __syncthreads();
+    if (threadIdx.x < DG_SECTIONS) atomicAdd(&a.sv->stats[RM_STAT_COUNT + threadIdx.x], (unsigned long long)diag_laps()[2 + threadIdx.x]);
+    if (threadIdx.x < 8) atomicAdd(&a.sv->stats[RM_STAT_COUNT + 8 + threadIdx.x], (unsigned long long)diag_kinds()[threadIdx.x]);
+    if (threadIdx.x == 0) {
+        const unsigned long long now = wall_clock64(), dur = now - wave_t0;
+        atomicMax(&a.sv->stats[24], dur);           // longest wave, in 10 ns ticks
+        atomicAdd(&a.sv->stats[25], dur);           // summed wave lifetimes
+        atomicMax(&a.sv->stats[26], ~wave_t0);      // first start (complemented) and last end of the grid
+        atomicMax(&a.sv->stats[27], now);
+        if (dur * 10 > 20000) atomicAdd(&a.sv->stats[28], 1ULL);  // waves longer than 20 us
+        if (dur * 10 > 50000) atomicAdd(&a.sv->stats[29], 1ULL);  // ... 50 us
+        if (dur * 10 > 100000) atomicAdd(&a.sv->stats[30], 1ULL); // ... 100 us
+    }
+#endif
 }
 
 // Primary march only: hit object, iteration count, final position.
@@ -379,6 +434,8 @@ struct rm_scene {
     float smooth_k = 0.0f;  // 0 = hard minimum (the reference's union)
 };
 
+constexpr int kStatSlots = 32;
+
 struct rm_engine {
     int device = 0;
     int W = 0, H = 0, M = 8;
@@ -407,7 +464,7 @@ struct rm_engine {
     TextureRec *d_tex = nullptr;
     std::vector<float *> d_texels;
     float *d_lightmaps = nullptr;  // [n_patches][3]
-    unsigned long long *d_stats = nullptr;
+    unsigned long long *d_stats = nullptr;  // kStatSlots words: RM_STAT_COUNT public ones, the rest for diagnostic builds
     unsigned char *d_frame = nullptr;  // W*H*4, for rm_engine_render
     unsigned char *h_stage = nullptr;  // pinned W*H*4 staging for callers that pass pageable memory
 
@@ -563,12 +620,21 @@ static int engine_upload(rm_engine *e) {
         }
     }
     const int n_boxes = (int)gi_box.size();
+    bool unit_dirs = true;  // every axis plane faces along +-1 (the march loop of the exact tier relies on it)
+    for (int a = 0; a < 3; a++)
+        for (size_t k = 0; k < gi_ax[a].size(); k++) unit_dirs = unit_dirs && fabsf(g_ax[a][2 * k + 1]) == 1.0f;
     auto fits = [&](int ns, int na, int ng) {
         return (int)gi_sph.size() <= ns && (int)gi_ax[0].size() <= na && (int)gi_ax[1].size() <= na &&
                (int)gi_ax[2].size() <= na && (int)gi_gp.size() <= ng;
     };
+    float sph_extent = 0.0f;
+    for (size_t k = 0; k < gi_sph.size(); k++) {
+        const float *c = &g_sph[4 * k];
+        sph_extent = fmaxf(sph_extent, fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fabsf(c[2])) + fabsf(c[3]));
+    }
     auto fill = [&](auto &gs) {
         memset(&gs, 0, sizeof(gs));
+        gs.sph_extent = sph_extent;
         gs.n_sph = (int)gi_sph.size();
         gs.n_x = (int)gi_ax[0].size();
         gs.n_y = (int)gi_ax[1].size();
@@ -593,7 +659,8 @@ static int engine_upload(rm_engine *e) {
     memset(&e->tier_x, 0, sizeof(e->tier_x));
     if (n_boxes > 0 || s.smooth_k > 0.0f) {
         e->tier = 2;  // boxes and smooth unions live in the large layout only
-    } else if (gi_sph.size() == 2 && gi_ax[0].size() == 2 && gi_ax[1].size() == 2 && gi_ax[2].size() == 2 && gi_gp.empty()) {
+    } else if (gi_sph.size() == 2 && gi_ax[0].size() == 2 && gi_ax[1].size() == 2 && gi_ax[2].size() == 2 && gi_gp.empty() &&
+               unit_dirs) {
         e->tier = -1;
         fill(e->tier_x);
     } else if (fits(GroupedTierA::kSpheres, GroupedTierA::kAxis, GroupedTierA::kPlanes)) {
@@ -615,6 +682,7 @@ static int engine_upload(rm_engine *e) {
         gl.n_gp = (int)gi_gp.size();
         gl.n_box = n_boxes;
         gl.smooth_k = s.smooth_k;
+        gl.sph_extent = sph_extent;
         auto up_i = [&](const std::vector<int> &v, const int **dst) -> hipError_t {
             int *d = nullptr;
             hipError_t err = dev_alloc(&d, v.size());
@@ -669,8 +737,8 @@ static int engine_upload(rm_engine *e) {
     HIP_TRY(hipMemset(e->d_lightmaps, 0, std::max<size_t>((size_t)e->n_patches * 3, 1) * sizeof(float)));
     HIP_TRY(dev_alloc(&e->d_view, 1));
     e->view_dirty = true;
-    HIP_TRY(dev_alloc(&e->d_stats, RM_STAT_COUNT));
-    HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * RM_STAT_COUNT));
+    HIP_TRY(dev_alloc(&e->d_stats, kStatSlots));
+    HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * kStatSlots));
     HIP_TRY(dev_alloc(&e->d_patch_obj, e->n_lm));
     if (e->n_lm)
         HIP_TRY(hipMemcpy(e->d_patch_obj, e->patch_obj.data(), sizeof(int) * e->n_lm, hipMemcpyHostToDevice));
@@ -1262,6 +1330,14 @@ int rm_engine_set_march_cap(rm_engine *e, int max_steps) {
     return RM_OK;
 }
 
+#ifdef RM_DIAG
+// Diagnostic builds only: the public counters followed by the per-section cycle sums.
+extern "C" int rm_diag_read(rm_engine *e, uint64_t out[kStatSlots]) {
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
+    return hipMemcpy(out, e->d_stats, sizeof(uint64_t) * kStatSlots, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int rm_engine_get_stats(rm_engine *e, uint64_t stats[RM_STAT_COUNT]) {
     if (!e || !stats) return fail(RM_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(e->device));
@@ -1274,7 +1350,7 @@ int rm_engine_reset_stats(rm_engine *e) {
     if (!e) return fail(RM_ERR_INVALID, "NULL engine");
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_ = sync_view(e)) return rc_;
-    HIP_TRY(hipMemsetAsync(e->d_stats, 0, sizeof(uint64_t) * RM_STAT_COUNT, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_stats, 0, sizeof(uint64_t) * kStatSlots, e->stream));
     return RM_OK;
 }
 

@@ -61,6 +61,7 @@ struct GroupedSmall {
     static constexpr int kSpheres = NS, kAxis = NA, kPlanes = NG;
     static constexpr bool kExact = EXACT;
     int n_sph, n_x, n_y, n_z, n_gp;
+    float sph_extent;  // largest |centre coordinate| + |radius| over the spheres (0 without spheres)
     int idx_sph[NS > 0 ? NS : 1];
     int idx_ax[3][NA > 0 ? NA : 1];
     int idx_gp[NG > 0 ? NG : 1];
@@ -68,7 +69,7 @@ struct GroupedSmall {
     float ax[3][NA > 0 ? NA : 1][2];   // offset, dir
     float gp[NG > 0 ? NG : 1][4];      // nx, ny, nz, distance
 };
-typedef GroupedSmall<2, 2, 0, true> GroupedTierX;  // exactly two spheres in an axis-aligned box of six planes
+typedef GroupedSmall<2, 2, 0, true> GroupedTierX;  // exactly two spheres and two planes per axis, each plane facing along +-1
 typedef GroupedSmall<2, 2, 0> GroupedTierA;
 typedef GroupedSmall<4, 4, 2> GroupedTierB;
 
@@ -87,6 +88,7 @@ struct GroupedLarge {
     // index within a group), which is part of the definition since the smooth minimum does not
     // associate.
     float smooth_k;
+    float sph_extent;  // as in GroupedSmall
 };
 
 struct SceneView {

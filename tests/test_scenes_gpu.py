@@ -19,6 +19,14 @@ def _room(extra, drop=(), smooth=0.0):
     return Scene(objects=list(extra) + objs, camera_position=base.camera_position, light=base.light, smooth_union=smooth)
 
 
+def _scaled_room():
+    base = default_scene()
+    objs = list(base.objects)
+    objs[4] = XPlane(-3.0, 0.5, MATT, SOFT_RED)
+    objs[6] = ZPlane(2.0, -0.75, MATT, SOFT_GRAY)
+    return Scene(objects=objs, camera_position=base.camera_position, light=base.light)
+
+
 GLOSSY = Material(0.1, 1.0, 0.9, 32.0, 0.25, 0.0)
 MIRROR = Material(0.05, 0.03, 0.2, 16.0, 1.0, 0.0)
 MATT = Material.basic()
@@ -36,6 +44,9 @@ SCENES = {
     # (matt spheres: a reflective surface inside a blend zone re-hits itself and recurses hundreds deep)
     "smooth_union": lambda: _room([Sphere((-1.2, -1.0, 0.1), 1.0, MATT, WHITE), Sphere((1.0, -1.0, -0.7), 1.0, Material(0.1, 1.0, 0.9, 32.0, 0.0, 0.0), SOFT_YELLOW),
                                    Box((0.2, -1.6, 0.6), (0.5, 0.4, 0.4), MATT, SOFT_RED)], drop=(0, 1), smooth=0.3),
+    # same counts as the default scene but plane directions other than +-1: must not take the
+    # exact tier's one-instruction plane distance
+    "scaled_dirs": lambda: _scaled_room(),
     # open scene: two planes removed, primary rays reach the sky (engine.rs:141)
     "open_sky": lambda: _room([], drop=(3, 6)),
 }

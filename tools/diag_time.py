@@ -1,0 +1,35 @@
+"""Wave start/end times of a -DRM_DIAG_TIME build: python tools/diag_time.py tools/librm_diagtime.so"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401
+
+from raymarching_amd import _lib, default_scene
+
+_lib.LIB_PATH = os.path.abspath(sys.argv[1])
+from raymarching_amd.engine import Engine
+
+W, H = int(os.environ.get("RM_W", 3840)), int(os.environ.get("RM_H", 2160))
+e = Engine(default_scene(), W, H)
+e.compute_lightmaps(4)
+for _ in range(3):
+    img = e.render(None, 0, 0, (0, 0, 0), 0)
+px = img.view(np.uint32).reshape(H, W)
+t0 = px[0::8, 0::8].astype(np.int64)
+t1 = px[0::8, 1::8].astype(np.int64)
+hw = px[0::8, 2::8]
+dur = ((t1 - t0) & 0xFFFFFFFF) / 100.0  # us
+start = ((t0 - t0.min()) & 0xFFFFFFFF) / 100.0
+end = start + dur
+print(f"waves {dur.size}: mean {dur.mean():.2f} us, median {np.median(dur):.2f}, p90 {np.percentile(dur, 90):.2f}, p99 {np.percentile(dur, 99):.2f}, max {dur.max():.2f}")
+print(f"grid span {end.max():.1f} us; sum of wave lifetimes {dur.sum() / 1e3:.1f} ms -> mean resident waves {dur.sum() / end.max():.0f}")
+for q in (50, 75, 90, 95, 99, 100):
+    print(f"  {q:3d} % of waves had ended by {np.percentile(end, q):.1f} us")
+order = np.argsort(end.ravel())[-8:]
+for i in order:
+    ty, tx = divmod(int(i), W // 8)
+    print(f"  late wave: tile ({tx},{ty}) start {start.ravel()[i]:.1f} us, lifetime {dur.ravel()[i]:.1f} us")
+np.save("gpurun_out/diag_time_dur.npy", dur.astype(np.float32))
+np.save("gpurun_out/diag_time_start.npy", start.astype(np.float32))

@@ -5,7 +5,11 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from raymarching_amd import Engine, default_scene
+from raymarching_amd import _lib, default_scene
+
+if os.environ.get("RM_LIB"):  # another build of the library (ablation and diagnostic variants)
+    _lib.LIB_PATH = os.path.abspath(os.environ["RM_LIB"])
+from raymarching_amd.engine import Engine
 
 W, H = int(os.environ.get("RM_W", 3840)), int(os.environ.get("RM_H", 2160))
 frames = int(os.environ.get("RM_FRAMES", 5))
