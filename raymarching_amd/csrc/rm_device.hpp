@@ -86,7 +86,8 @@ RM_DEV V3 emul(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
 // vector.rs:24: ordered lane sum of squares; the fourth lane is 0 whenever the
 // other three are not already NaN, so it never changes the sum.
 RM_DEV float mag_sqd(V3 a) { return (a.x * a.x + a.y * a.y) + a.z * a.z; }
-RM_DEV float mag(V3 a) { return sqrtf(mag_sqd(a)); }  // vector.rs:22
+RM_DEV float sqrt_rn(float x);
+RM_DEV float mag(V3 a) { return sqrt_rn(mag_sqd(a)); }  // vector.rs:22
 // vector.rs:27-30: reciprocal then multiply
 RM_DEV V3 normalized(V3 a) {
     float inv = 1.0f / mag(a);
@@ -519,15 +520,29 @@ RM_DEV float smooth_shadow_march(const SC &sc, V3 pos, V3 dir, int ignore, float
     return shadow_with(sc, pos, dir, LaneIgnore{ignore}, light_dist, k);
 }
 
-// objects.rs:135-141 for a per-lane object
+// objects.rs:135-141 for a per-lane object.  The six evaluations sit inside one dispatch on the
+// type, so a wave runs them only for the types its lanes hold.
+template <int TYPE>
+RM_DEV V3 central_differences(const Geom &g, V3 p) {
+    float gx = sdf_eval(TYPE, g, v3(p.x + STEP_SIZE, p.y + 0.0f, p.z + 0.0f)) -
+               sdf_eval(TYPE, g, v3(p.x - STEP_SIZE, p.y - 0.0f, p.z - 0.0f));
+    float gy = sdf_eval(TYPE, g, v3(p.x + 0.0f, p.y + STEP_SIZE, p.z + 0.0f)) -
+               sdf_eval(TYPE, g, v3(p.x - 0.0f, p.y - STEP_SIZE, p.z - 0.0f));
+    float gz = sdf_eval(TYPE, g, v3(p.x + 0.0f, p.y + 0.0f, p.z + STEP_SIZE)) -
+               sdf_eval(TYPE, g, v3(p.x - 0.0f, p.y - 0.0f, p.z - STEP_SIZE));
+    return v3(gx, gy, gz);
+}
 RM_DEV V3 calculate_normal(int type, const Geom &g, V3 p) {
-    float gx = sdf_eval(type, g, v3(p.x + STEP_SIZE, p.y + 0.0f, p.z + 0.0f)) -
-               sdf_eval(type, g, v3(p.x - STEP_SIZE, p.y - 0.0f, p.z - 0.0f));
-    float gy = sdf_eval(type, g, v3(p.x + 0.0f, p.y + STEP_SIZE, p.z + 0.0f)) -
-               sdf_eval(type, g, v3(p.x - 0.0f, p.y - STEP_SIZE, p.z - 0.0f));
-    float gz = sdf_eval(type, g, v3(p.x + 0.0f, p.y + 0.0f, p.z + STEP_SIZE)) -
-               sdf_eval(type, g, v3(p.x - 0.0f, p.y - 0.0f, p.z - STEP_SIZE));
-    return normalized(v3(gx, gy, gz));
+    V3 grad;
+    switch (type) {
+        case T_SPHERE: grad = central_differences<T_SPHERE>(g, p); break;
+        case T_XPLANE: grad = central_differences<T_XPLANE>(g, p); break;
+        case T_YPLANE: grad = central_differences<T_YPLANE>(g, p); break;
+        case T_ZPLANE: grad = central_differences<T_ZPLANE>(g, p); break;
+        case T_PLANE: grad = central_differences<T_PLANE>(g, p); break;
+        default: grad = central_differences<T_BOX>(g, p); break;
+    }
+    return normalized(grad);
 }
 
 // objects.rs:285-290, 305-310, 325-330, 353-358
@@ -814,7 +829,7 @@ RM_DEV unsigned to_pixel_range(float i) {
 RM_DEV unsigned pack_pixel(V3 linear, float exposure) {
     V3 c = linear * exposure;
     if (RM_ABL & 16) return to_pixel_range(c.x) | (to_pixel_range(c.y) << 8) | (to_pixel_range(c.z) << 16);
-    float r = sqrtf(aces(c.x)), g = sqrtf(aces(c.y)), b = sqrtf(aces(c.z));
+    float r = sqrt_rn(aces(c.x)), g = sqrt_rn(aces(c.y)), b = sqrt_rn(aces(c.z));
     return to_pixel_range(b) | (to_pixel_range(g) << 8) | (to_pixel_range(r) << 16);
 }
 
