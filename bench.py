@@ -34,6 +34,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--fxaa", action="store_true", help="add the FXAA pass to every frame")
+    ap.add_argument("--ssaa", action="store_true", help="four rays per pixel (the supersampling the reference carries commented out)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the CPU baseline leg")
     ap.add_argument("--no-overlap", action="store_true", help="wait for each frame's all-gather before the next render")
@@ -217,6 +218,9 @@ def main():
     else:
         eng.compute_lightmaps(4)  # main.rs:73: once, before the frame loop (not timed)
     eng.input(0, 0, (0.0, 0.0, 0.0), 0)  # first-frame pose (main.rs:78-80,122)
+    if args.ssaa:
+        eng.set_ssaa(4)
+        args.no_cpu_baseline = True  # parity of this mode is covered by tests/test_render_gpu.py
 
     # Sharding: without FXAA rank r renders the 8-row strips r, r+N, r+2N, ... (even load however
     # the cost is spread over the image); with FXAA it renders one contiguous band plus the few rows
@@ -324,9 +328,9 @@ def main():
 
     result = None
     if rank == 0:
-        rays = W * H
+        rays = W * H * (4 if args.ssaa else 1)
         ms_per_step = elapsed / args.steps * 1e3
-        counters = load_counters(W, H) if args.workload == "render" else None
+        counters = load_counters(W, H) if args.workload == "render" and not args.ssaa else None
         roofline = None
         if counters is not None:
             band_share = (r1 - r0) / H  # flops are counted for the whole frame; a band is its share by rows
@@ -362,12 +366,13 @@ def main():
             "config": {
                 "workload": (f"default scene {W}x{H}, march + shading + texture + lightmap + reflections" if args.workload == "render"
                              else f"stress scene: 250 spheres and boxes + room, smooth union k=0.08, {W}x{H}, march cap 1024")
-                + (" + FXAA" if args.fxaa else ""),
+                + (" + FXAA" if args.fxaa else "") + (", 4 rays per pixel" if args.ssaa else ""),
                 "width": W,
                 "height": H,
                 "bands": world,
                 "sharding": "interleaved 8-row strips" if interleaved else "contiguous row bands",
                 "fxaa": bool(args.fxaa),
+                "ssaa": 4 if args.ssaa else 1,
                 "map_size": 8,
                 "overlap_gather": world > 1 and not args.no_overlap,
             },

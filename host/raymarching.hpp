@@ -192,6 +192,9 @@ class Engine {
         check(rm_engine_render(handle_, buffer, pitch, mouse_x, mouse_y, &rel_move.x, scroll), "render");
     }
 
+    // engine.rs:95-108 (commented out there): four rays per pixel
+    void set_ssaa(bool on) { check(rm_engine_set_ssaa(handle_, on ? 4 : 1), "set_ssaa"); }
+
     Vec3 camera_position() const {
         Vec3 p;
         check(rm_engine_get_camera(handle_, &p.x), "get_camera");

@@ -211,6 +211,12 @@ int rm_engine_trace_primary(rm_engine *engine, int32_t *hit, int32_t *steps, flo
 int rm_engine_probe_shade(rm_engine *engine, int n, const int32_t *object, const float *position,
                           const float *direction, float *colour);
 
+/* Supersampling, engine.rs:95-108 (commented out in the reference): samples = 4 casts four rays per
+ * pixel - the pixel's direction moved by (+-0.5/WIDTH, 0, 0) and (0, +-0.5/HEIGHT, 0) before it is
+ * normalised - and averages their linear colours ((c0 + c1) + c2 + c3) / 4 ahead of tone mapping.
+ * samples = 1 (the default) is the reference's live path.  Applies to every render entry point. */
+int rm_engine_set_ssaa(rm_engine *engine, int samples);
+
 /* Optional divergence cap on march iterations (0 = none; the loop of ray.rs:19
  * ends by itself after at most 50/0.001 steps).  Cut marches are counted. */
 int rm_engine_set_march_cap(rm_engine *engine, int max_steps);

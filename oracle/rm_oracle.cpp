@@ -744,6 +744,7 @@ struct Engine {
     PointLight light;
     int map_size = 8;
     float smooth_k = 0.0f;  // EXTENSION, see Ray::smooth_k
+    int ssaa = 1;           // 4 = the four-ray supersampling of engine.rs:95-108 (commented out there)
     mutable std::vector<uint64_t> fold_order;
     const std::vector<uint64_t> *order() const {
         if (fold_order.size() != objects.size()) {
@@ -864,7 +865,17 @@ struct Engine {
                 for (int x = 0; x < W; x++) {
                     CNT(pixels, 1);
                     Vec3 dir = pixel_direction(pose, W, H, x, y_inv);
-                    Colour colour_linear = cast_sight_ray(camera_position, dir, 0);
+                    Colour colour_linear;
+                    if (ssaa == 4) {
+                        // engine.rs:95-108 (commented out there)
+                        const Vec3 offsets[4] = {Vec3(0.5f / (float)W, 0.0f / (float)H, 0.0f), Vec3(-0.5f / (float)W, 0.0f / (float)H, 0.0f),
+                                                 Vec3(0.0f / (float)W, 0.5f / (float)H, 0.0f), Vec3(0.0f / (float)W, -0.5f / (float)H, 0.0f)};
+                        Colour c[4];
+                        for (int i = 0; i < 4; i++) c[i] = cast_sight_ray(camera_position, (dir + offsets[i]).normalized(), 0);
+                        colour_linear = (c[0] + c[1] + c[2] + c[3]) / 4.0f;
+                    } else {
+                        colour_linear = cast_sight_ray(camera_position, dir, 0);
+                    }
                     Colour colour_srgb = aces_film(colour_linear * pose.exposure).sqrt();  // engine.rs:110
                     uint8_t *px = buffer + ((size_t)((y_inv - row0) / row_step) * W + x) * 4;
                     px[0] = to_pixel_range(colour_srgb.z());  // engine.rs:120-125
@@ -1195,6 +1206,7 @@ int orc_add_box(void *h, const float *pos, const float *half, const float *mat, 
     return (int)e->objects.size() - 1;
 }
 void orc_set_smooth_union(void *h, float k) { static_cast<Engine *>(h)->smooth_k = k; }
+void orc_set_ssaa(void *h, int samples) { static_cast<Engine *>(h)->ssaa = samples; }
 float orc_kat_smooth_min(float a, float b, float k) { return smooth_min(a, b, k); }
 void orc_set_light(void *h, const float *pos, float intensity) {
     Engine *e = static_cast<Engine *>(h);

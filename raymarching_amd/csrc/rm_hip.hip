@@ -122,6 +122,26 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderArgs 
 #endif
 }
 
+// engine.rs:95-108 (disabled in the reference): four rays per pixel, half a pixel step left, right,
+// up and down of the pixel's direction before normalising, averaged in that order.
+template <class G>
+__global__ __launch_bounds__(BLOCK_THREADS) void render_ssaa_kernel(const RenderArgs a, const G g) {
+    int x, y_inv, out_row;
+    tile_pixel(a, x, y_inv, out_row);
+    if (x >= a.pose.W || y_inv >= a.row_end) return;
+    const V3 dir = pixel_direction(a.pose, x, y_inv);
+    const V3 cam = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
+    const float ox = 0.5f / (float)a.pose.W, oy = 0.5f / (float)a.pose.H;
+    V3 sum = v3(0.0f, 0.0f, 0.0f);
+    for (int i = 0; i < 4; i++) {
+        const V3 off = i == 0 ? v3(ox, 0.0f, 0.0f) : i == 1 ? v3(-ox, 0.0f, 0.0f) : i == 2 ? v3(0.0f, oy, 0.0f) : v3(0.0f, -oy, 0.0f);
+        const V3 c = cast_sight_ray(acc_of(g), *a.sv, cam, normalized(dir + off));
+        sum = i == 0 ? c : sum + c;
+    }
+    unsigned px = pack_pixel(sum / 4.0f, a.pose.exposure);
+    *reinterpret_cast<unsigned *>(a.out + (size_t)out_row * a.pitch + (size_t)x * 4) = px;
+}
+
 // Primary march only: hit object, iteration count, final position.
 template <class G>
 __global__ __launch_bounds__(BLOCK_THREADS) void trace_kernel(const RenderArgs a, int *hit, int *steps_out,
@@ -444,6 +464,7 @@ struct rm_engine {
     float camera[3];
     Pose pose;
     int march_cap = 0;
+    bool ssaa = false;  // four rays per pixel (engine.rs:95-108)
 
     // device-resident scene
     int n = 0, n_lm = 0, n_patches = 0;
@@ -1016,7 +1037,10 @@ int rm_engine_render_rows_device(rm_engine *e, void *d_bgra, size_t pitch_bytes,
     if (int rc_ = sync_view(e)) return rc_;
     dim3 grid;
     RenderArgs a = make_render_args(e, d_bgra, pitch_bytes, row_begin, row_end, grid);
-    RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);
+    if (e->ssaa)
+        RM_LAUNCH(render_ssaa_kernel, e, grid, dim3(BLOCK_THREADS), a);
+    else
+        RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);
     HIP_TRY(hipGetLastError());
     return RM_OK;
 }
@@ -1034,7 +1058,10 @@ int rm_engine_render_strips_device(rm_engine *e, void *d_bgra, size_t pitch_byte
     a.blocks_y = n_strips;
     a.tile_row_stride = strip_stride;
     grid = dim3((unsigned)(a.blocks_x * a.blocks_y), 1, 1);
-    RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);
+    if (e->ssaa)
+        RM_LAUNCH(render_ssaa_kernel, e, grid, dim3(BLOCK_THREADS), a);
+    else
+        RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);
     HIP_TRY(hipGetLastError());
     return RM_OK;
 }
@@ -1320,6 +1347,12 @@ int rm_engine_set_lightmap(rm_engine *e, int object, const float *values) {
     size_t count = (size_t)e->M * e->M * 3;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->d_lightmaps + slot * count, values, count * sizeof(float), hipMemcpyHostToDevice));
+    return RM_OK;
+}
+
+int rm_engine_set_ssaa(rm_engine *e, int samples) {
+    if (!e || (samples != 1 && samples != 4)) return fail(RM_ERR_INVALID, "samples must be 1 or 4");
+    e->ssaa = samples == 4;
     return RM_OK;
 }
 

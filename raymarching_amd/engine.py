@@ -214,6 +214,10 @@ class Engine:
         )
         return out
 
+    def set_ssaa(self, samples):
+        """engine.rs:95-108: 4 = four rays per pixel, averaged; 1 = off."""
+        _lib.check(self.lib.rm_engine_set_ssaa(self.handle, samples), "rm_engine_set_ssaa")
+
     def set_march_cap(self, max_steps):
         _lib.check(self.lib.rm_engine_set_march_cap(self.handle, max_steps), "rm_engine_set_march_cap")
 

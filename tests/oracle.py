@@ -51,6 +51,7 @@ def load(counting=False):
     lib.orc_add_plane.argtypes = [c_void_p, _F, c_float, _F, _F]
     lib.orc_add_box.argtypes = [c_void_p, _F, _F, _F, _F]
     lib.orc_set_smooth_union.argtypes = [c_void_p, c_float]
+    lib.orc_set_ssaa.argtypes = [c_void_p, c_int]
     lib.orc_kat_smooth_min.restype = c_float
     lib.orc_kat_smooth_min.argtypes = [c_float, c_float, c_float]
     lib.orc_set_light.argtypes = [c_void_p, _F, c_float]
@@ -136,6 +137,9 @@ class OracleEngine:
 
     def set_smooth_union(self, k):
         self.lib.orc_set_smooth_union(self.handle, k)
+
+    def set_ssaa(self, samples):
+        self.lib.orc_set_ssaa(self.handle, samples)
 
     def set_light(self, pos, intensity):
         self.lib.orc_set_light(self.handle, _fa(pos), intensity)

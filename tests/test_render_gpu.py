@@ -171,6 +171,32 @@ def test_headless_host_harness(tmp_path, scene, oracle_lightmaps):
     assert_frames_match(got, ref, "headless harness")
 
 
+def test_supersampled_frame(scene, oracle_lightmaps):
+    """The four-ray supersampling the reference carries commented out (engine.rs:95-108): same
+    tolerance as the live path, at two poses."""
+    from raymarching_amd import Engine
+
+    w, h = 240, 180
+    lm, _ = oracle_lightmaps
+    ora = make_oracle(scene, lm[-1])
+    ora.set_ssaa(4)
+    eng = Engine(scene, w, h)
+    for i in range(eng.n_objects):
+        eng.set_lightmap(i, lm[-1][i])
+    eng.set_ssaa(4)
+    for pose in [(0, 0, (0.0, 0.0, 0.0), 0), (-140, 60, (0.3, 0.0, 0.6), 2)]:
+        got = eng.render(None, *pose)
+        ref = ora.render(w, h, *pose)
+        mx, exact = assert_frames_match(got, ref, f"ssaa {pose}")
+        print(f"ssaa pose {pose}: max|d|={mx} exact={exact:.5%}")
+    eng.set_ssaa(1)
+    ora.set_ssaa(1)
+    assert_frames_match(eng.render(None), ora.render(w, h), "ssaa off again")
+    with pytest.raises(Exception, match="1 or 4"):
+        eng.set_ssaa(3)
+    eng.close()
+
+
 def test_frame_sequence_with_recorded_input(scene, oracle_lightmaps):
     """A recorded input trace (mouse look, WASD movement, scroll zoom; main.rs:105-138) played
     through the pipelined rm_engine_render_async path: every frame and the final camera match the
