@@ -197,6 +197,7 @@ struct SceneSmallAcc {
     template <class F>
     RM_DEV void boxes(F &&) const {}  // scenes with boxes or smooth unions use the large layout
     static constexpr bool kSmooth = false;
+    static constexpr bool kGrid = false;
     RM_DEV float sphere_extent() const { return g.sph_extent; }
     static constexpr bool kUnitAxis = G::kExact;  // the exact-fill tier also promises |dir| = 1 on every axis plane
     RM_DEV float smooth_k() const { return 0.0f; }
@@ -227,6 +228,8 @@ struct SceneLargeAcc {
         }
     }
     static constexpr bool kSmooth = true;
+    static constexpr bool kGrid = true;
+    RM_DEV const GridView &grid() const { return g.grid; }
     RM_DEV float sphere_extent() const { return g.sph_extent; }
     static constexpr bool kUnitAxis = false;
     RM_DEV float smooth_k() const { return g.smooth_k; }
@@ -304,6 +307,77 @@ RM_DEV float box_sdf(V3 c, V3 h, V3 p) {
     return sqrt_rn(mag_sqd(r)) + rs_min(rs_max(q.x, rs_max(q.y, q.z)), 0.0f);
 }
 
+// Spatial index lookup for a point: the list ranges of its cell, empty for a point outside the
+// grid (or a NaN).
+struct CellLists {
+    int s0, s1, b0, b1;
+};
+RM_DEV CellLists grid_cell(const GridView &gv, V3 p) {
+    const float fx = (p.x - gv.ox) * gv.inv_cell, fy = (p.y - gv.oy) * gv.inv_cell, fz = (p.z - gv.oz) * gv.inv_cell;
+    const bool inside = fx >= 0.0f && fx < (float)gv.nx && fy >= 0.0f && fy < (float)gv.ny && fz >= 0.0f && fz < (float)gv.nz;
+    CellLists c = {0, 0, 0, 0};
+    if (inside) {
+        const int cell = ((int)fz * gv.ny + (int)fy) * gv.nx + (int)fx;  // non-negative: truncation is floor
+        c.s0 = gv.sph_start[cell];
+        c.s1 = gv.sph_start[cell + 1];
+        c.b0 = gv.box_start[cell];
+        c.b1 = gv.box_start[cell + 1];
+    }
+    return c;
+}
+
+// The sphere and box part of the fold below, done over the lists of p's grid cell only.  Returns
+// whether the value is certain to equal the fold over every sphere and box; `r` enters as the value
+// after the planes and leaves as the result.
+//
+// Every primitive missing from the lists is at least R = reach away.
+//   * Hard minimum: if the minimum over planes and listed primitives is <= R, no missing one can
+//     lower it.
+//   * Smooth minimum, folded in order: a missing primitive is a no-op whenever the running value is
+//     <= R - k at its turn, and the running value never rises.  That holds from the start if the
+//     planes already bring it there.  Otherwise the fold over the listed primitives may differ from
+//     the full one until a listed primitive with distance s arrives that lies 2k below everything
+//     folded before it (planes, listed ones, and R for the missing ones): a running value is never
+//     more than k below the minimum of what was folded, so at that turn the gap is >= k in both
+//     folds, both take exactly s (<= R - 2k), and from there on they agree.  (`slack` keeps the
+//     comparison clear of the rounding of the two sums.)
+template <class SC, class IGN>
+RM_DEV bool grid_fold(const SC &sc, V3 p, const IGN &ign, float &r, float k, bool blend) {
+    const GridView &gv = sc.grid();
+    const CellLists c = grid_cell(gv, p);
+    const float R = gv.reach;
+    bool certain = r <= R - k;  // blend only
+    float floor_before = rs_min(r, R);
+    const float slack = 2.01f * k + 1e-4f;
+    auto fold = [&](float s) {
+        if (blend) {
+            if (s + slack <= floor_before) {
+                r = s;
+                certain = true;
+            } else {
+                r = smooth_min(r, s, k);
+            }
+            floor_before = rs_min(floor_before, s);
+        } else {
+            r = rs_min(r, s);
+        }
+    };
+    for (int e = c.s0; e < c.s1; e++) {
+        const float4 g = reinterpret_cast<const float4 *>(gv.sph_geom)[e];
+        const int oi = gv.sph_index[e];
+        const float s = sqrt_rn(mag_sqd(p - v3(g.x, g.y, g.z))) - g.w;
+        fold(ign.skip(oi) ? __builtin_inff() : ign.mask(oi, s));
+    }
+    for (int e = c.b0; e < c.b1; e++) {
+        const float4 g0 = reinterpret_cast<const float4 *>(gv.box_geom)[2 * e];
+        const float4 g1 = reinterpret_cast<const float4 *>(gv.box_geom)[2 * e + 1];
+        const int oi = gv.box_index[e];
+        const float s = box_sdf(v3(g0.x, g0.y, g0.z), v3(g0.w, g1.x, g1.y), p);
+        fold(ign.skip(oi) ? __builtin_inff() : ign.mask(oi, s));
+    }
+    return blend ? certain : (r <= R);
+}
+
 // The value `distance` holds after the object loop of ray.rs:23-33 / 98-107: the minimum over
 // objects of sdf(p) - or, with a smooth union (extension), their smooth-minimum fold in group
 // order.
@@ -343,6 +417,14 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, bool active, SphereBo
     sc.planes([&](int oi, float nx, float ny, float nz, float dist) {
         if (!ign.skip(oi)) fold(ign.mask(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist));
     });
+    if constexpr (SC::kGrid) {
+        if (sc.grid().cells > 0) {
+            if (!active) return d;
+            float r = d;
+            if (grid_fold(sc, p, ign, r, k, blend)) return r;
+            // not certain from the cell's lists alone: the full walk below settles it
+        }
+    }
     // spheres: the whole group is skipped while the carried bound proves it irrelevant (with a
     // smooth union a sphere matters only within k of the running value)
     const float reach = __builtin_fmaf(travelled, sb.dn, blend ? d + k : d);
@@ -393,6 +475,26 @@ RM_DEV int closest_index(const SC &sc, V3 p, float, const IGN &ign) {
     sc.planes([&](int oi, float nx, float ny, float nz, float dist) {
         if (!ign.skip(oi)) take(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist);
     });
+    if constexpr (SC::kGrid) {
+        if (sc.grid().cells > 0) {
+            // the primitives missing from the cell's lists are at least `reach` away: a best
+            // distance below that cannot be theirs
+            const GridView &gv = sc.grid();
+            const CellLists c = grid_cell(gv, p);
+            for (int e = c.s0; e < c.s1; e++) {
+                const float4 g = reinterpret_cast<const float4 *>(gv.sph_geom)[e];
+                const int oi = gv.sph_index[e];
+                if (!ign.skip(oi)) take(oi, sqrt_rn(mag_sqd(p - v3(g.x, g.y, g.z))) - g.w);
+            }
+            for (int e = c.b0; e < c.b1; e++) {
+                const float4 g0 = reinterpret_cast<const float4 *>(gv.box_geom)[2 * e];
+                const float4 g1 = reinterpret_cast<const float4 *>(gv.box_geom)[2 * e + 1];
+                const int oi = gv.box_index[e];
+                if (!ign.skip(oi)) take(oi, box_sdf(v3(g0.x, g0.y, g0.z), v3(g0.w, g1.x, g1.y), p));
+            }
+            if (best < gv.reach) return bi;
+        }
+    }
     sc.spheres([&](int, int oi, float cx, float cy, float cz, float r) {
         if (!ign.skip(oi)) take(oi, sqrt_rn(mag_sqd(p - v3(cx, cy, cz))) - r);
     });

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -455,6 +456,8 @@ struct rm_scene {
 };
 
 constexpr int kStatSlots = 32;
+constexpr int kGridMinPrimitives = 16;  // fewer bounded primitives than this: no spatial index
+constexpr int kGridMaxDim = 48;         // cells per axis at most
 
 struct rm_engine {
     int device = 0;
@@ -465,6 +468,7 @@ struct rm_engine {
     Pose pose;
     int march_cap = 0;
     bool ssaa = false;  // four rays per pixel (engine.rs:95-108)
+    size_t grid_entries = 0;  // list entries of the spatial index (0 = none)
 
     // device-resident scene
     int n = 0, n_lm = 0, n_patches = 0;
@@ -730,6 +734,108 @@ static int engine_upload(rm_engine *e) {
         HIP_TRY(up_f(g_gp, &gl.gp));
         HIP_TRY(up_i(gi_box, &gl.idx_box));
         HIP_TRY(up_f(g_box, &gl.box));
+
+        // Spatial index (see GridView) once the bounded primitives are many enough to pay for it.
+        const int n_bounded = (int)gi_sph.size() + n_boxes;
+        if (n_bounded >= kGridMinPrimitives) {
+            // bounds of every primitive
+            std::vector<float> lo(3 * n_bounded), hi(3 * n_bounded);
+            float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int i = 0; i < n_bounded; i++) {
+                const bool is_sphere = i < (int)gi_sph.size();
+                const float *g = is_sphere ? &g_sph[4 * i] : &g_box[8 * (i - gi_sph.size())];
+                for (int a = 0; a < 3; a++) {
+                    const float ext = is_sphere ? fabsf(g[3]) : fabsf(g[3 + a]);
+                    lo[3 * i + a] = g[a] - ext;
+                    hi[3 * i + a] = g[a] + ext;
+                    blo[a] = fminf(blo[a], lo[3 * i + a]);
+                    bhi[a] = fmaxf(bhi[a], hi[3 * i + a]);
+                }
+            }
+            bool finite = true;
+            for (int a = 0; a < 3; a++) finite = finite && std::isfinite(blo[a]) && std::isfinite(bhi[a]);
+            const double ex[3] = {(double)bhi[0] - blo[0], (double)bhi[1] - blo[1], (double)bhi[2] - blo[2]};
+            const double longest = std::max(ex[0], std::max(ex[1], ex[2]));
+            if (finite && longest > 0.0) {
+                // mean spacing of the primitives; cells a quarter of it, reach 0.85 of it plus the blend width
+                // (the fastest of a sweep over both on the 250-primitive stress scenes: longer lists cost more
+                // than the full walks that shorter ones cause)
+                const double vol = std::max(ex[0], 0.05 * longest) * std::max(ex[1], 0.05 * longest) * std::max(ex[2], 0.05 * longest);
+                const double spacing = std::cbrt(vol / n_bounded);
+                const double reach_mul = getenv("RM_GRID_REACH") ? atof(getenv("RM_GRID_REACH")) : 0.85;  // tuning aid
+                const double cell_mul = getenv("RM_GRID_CELL") ? atof(getenv("RM_GRID_CELL")) : 0.25;
+                const float reach = (float)(reach_mul * spacing + 2.0 * s.smooth_k);
+                float cell = (float)(cell_mul * spacing);
+                cell = fmaxf(cell, (float)((longest + 2.0 * reach) / kGridMaxDim));
+                const float scale = fmaxf(fmaxf(fabsf(blo[0]), fabsf(bhi[0])), fmaxf(fmaxf(fabsf(blo[1]), fabsf(bhi[1])), fmaxf(fabsf(blo[2]), fabsf(bhi[2])))) + reach;
+                const float margin = 1e-3f + 1e-5f * scale;  // rounding of the cell lookup and of the distances
+                GridView gv;
+                memset(&gv, 0, sizeof(gv));
+                gv.ox = blo[0] - reach - margin;
+                gv.oy = blo[1] - reach - margin;
+                gv.oz = blo[2] - reach - margin;
+                gv.inv_cell = 1.0f / cell;
+                gv.reach = reach;
+                gv.nx = std::max(1, (int)std::ceil((bhi[0] + reach + margin - gv.ox) / cell));
+                gv.ny = std::max(1, (int)std::ceil((bhi[1] + reach + margin - gv.oy) / cell));
+                gv.nz = std::max(1, (int)std::ceil((bhi[2] + reach + margin - gv.oz) / cell));
+                gv.cells = gv.nx * gv.ny * gv.nz;
+                std::vector<int> s_start(gv.cells + 1, 0), b_start(gv.cells + 1, 0), s_index, b_index;
+                std::vector<float> s_geom, b_geom;
+                const float origin[3] = {gv.ox, gv.oy, gv.oz};
+                for (int cz = 0; cz < gv.nz; cz++)
+                    for (int cy = 0; cy < gv.ny; cy++)
+                        for (int cx = 0; cx < gv.nx; cx++) {
+                            const int c = (cz * gv.ny + cy) * gv.nx + cx;
+                            const int ci[3] = {cx, cy, cz};
+                            float clo[3], chi[3];
+                            for (int a = 0; a < 3; a++) {
+                                // the device computes the cell as floor((p - origin) * inv_cell): widen by the margin
+                                clo[a] = origin[a] + (float)ci[a] * cell - margin;
+                                chi[a] = origin[a] + (float)(ci[a] + 1) * cell + margin;
+                            }
+                            for (int i = 0; i < n_bounded; i++) {
+                                const bool is_sphere = i < (int)gi_sph.size();
+                                double d2 = 0.0;  // squared distance between the cell and the primitive's bounds
+                                if (is_sphere) {
+                                    const float *g = &g_sph[4 * i];
+                                    for (int a = 0; a < 3; a++) {
+                                        const double t = std::max(0.0, std::max((double)clo[a] - g[a], (double)g[a] - chi[a]));
+                                        d2 += t * t;
+                                    }
+                                    const double d = std::sqrt(d2) - fabs((double)g[3]);
+                                    if (d < (double)reach + margin) {
+                                        s_index.push_back(gi_sph[i]);
+                                        s_geom.insert(s_geom.end(), g, g + 4);
+                                    }
+                                } else {
+                                    const int b = i - (int)gi_sph.size();
+                                    for (int a = 0; a < 3; a++) {
+                                        const double t = std::max(0.0, std::max((double)clo[a] - hi[3 * i + a], (double)lo[3 * i + a] - chi[a]));
+                                        d2 += t * t;
+                                    }
+                                    if (std::sqrt(d2) < (double)reach + margin) {
+                                        b_index.push_back(gi_box[b]);
+                                        b_geom.insert(b_geom.end(), &g_box[8 * b], &g_box[8 * b] + 8);
+                                    }
+                                }
+                            }
+                            s_start[c + 1] = (int)s_index.size();
+                            b_start[c + 1] = (int)b_index.size();
+                        }
+                HIP_TRY(up_i(s_start, &gv.sph_start));
+                HIP_TRY(up_f(s_geom, &gv.sph_geom));
+                HIP_TRY(up_i(s_index, &gv.sph_index));
+                HIP_TRY(up_i(b_start, &gv.box_start));
+                HIP_TRY(up_f(b_geom, &gv.box_geom));
+                HIP_TRY(up_i(b_index, &gv.box_index));
+                gl.grid = gv;
+                e->grid_entries = s_index.size() + b_index.size();
+                if (getenv("RM_VERBOSE"))
+                    fprintf(stderr, "rm: spatial index %d x %d x %d cells of %.3f, reach %.3f, %zu entries (%.1f per cell) for %d primitives\n",
+                            gv.nx, gv.ny, gv.nz, cell, reach, e->grid_entries, (double)e->grid_entries / gv.cells, n_bounded);
+            }
+        }
     }
     e->n_lm = (int)e->patch_obj.size();
     e->n_patches = e->n_lm * e->M * e->M;

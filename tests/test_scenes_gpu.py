@@ -27,6 +27,28 @@ def _scaled_room():
     return Scene(objects=objs, camera_position=base.camera_position, light=base.light)
 
 
+def _scatter(n, boxes, matt=False):
+    """n small primitives in the room, clear of each other and of the two default spheres (surfaces
+    inside one another make mirror chains hundreds of bounces long)."""
+    rng = np.random.default_rng(11)
+    placed = [((-1.2, -1.0, 0.1), 1.0), ((1.0, -1.0, -0.7), 1.0)]
+    out = []
+    while len(out) < n:
+        c = tuple(float(v) for v in rng.uniform([-2.4, -1.4, -0.5], [2.4, 2.8, 1.6]))
+        r = float(rng.uniform(0.12, 0.3))
+        if any(np.linalg.norm(np.subtract(c, pc)) < r + pr + 0.05 for pc, pr in placed):
+            continue
+        placed.append((c, r))
+        i = len(out)
+        mat = MATT if matt else [MIRROR, GLOSSY, MATT][i % 3]
+        if boxes and i % 2:
+            h = r / np.sqrt(3.0)
+            out.append(Box(c, (float(1.2 * h), float(0.8 * h), float(h)), mat, SOFT_RED))
+        else:
+            out.append(Sphere(c, r, mat, [WHITE, SOFT_GREEN, SOFT_YELLOW][i % 3]))
+    return out
+
+
 GLOSSY = Material(0.1, 1.0, 0.9, 32.0, 0.25, 0.0)
 MIRROR = Material(0.05, 0.03, 0.2, 16.0, 1.0, 0.0)
 MATT = Material.basic()
@@ -47,6 +69,11 @@ SCENES = {
     # same counts as the default scene but plane directions other than +-1: must not take the
     # exact tier's one-instruction plane distance
     "scaled_dirs": lambda: _scaled_room(),
+    # enough bounded primitives for the spatial index (16 or more), in an open scene: rays leave the
+    # grid, reflections and shadow rays start on listed primitives
+    "grid_sparse_open": lambda: _room(_scatter(16, boxes=False), drop=(3, 6)),
+    # the same with boxes and a wide blend: the ordered smooth fold over cell lists
+    "grid_smooth": lambda: _room(_scatter(20, boxes=True, matt=True), drop=(0, 1), smooth=0.15),
     # open scene: two planes removed, primary rays reach the sky (engine.rs:141)
     "open_sky": lambda: _room([], drop=(3, 6)),
 }
@@ -93,7 +120,7 @@ def test_scene_tiers(name):
     mx, exact = assert_frames_match(got, ref, name)
     print(f"{name}: max|d|={mx} exact={exact:.5%} caps={st}")
     assert st["depth_cap_hits"] == 0
-    if name == "open_sky":
+    if name in ("open_sky", "grid_sparse_open"):
         # with walls missing many luxels stay empty and the reference's resampling leaves the map
         # (it would abort); both sides clamp such fetches the same way and count them
         assert (hit < 0).any(), "no primary ray reached the sky"
