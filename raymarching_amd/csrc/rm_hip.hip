@@ -262,9 +262,9 @@ __global__ void rad_direct_kernel(const RadArgs a, const G grp) {
 // radiosity.rs:119-152 for one (receiver i, source j) pair: everything of the
 // inner loop that does not depend on the bounce.  x = receiver, y = source.
 template <class G>
-__global__ void rad_form_kernel(const RadArgs a, int p0, int p1, const G grp) {
+__global__ void rad_form_kernel(const RadArgs a, int p0, int p1, int j0, const G grp) {
     int i = p0 + blockIdx.x * blockDim.x + threadIdx.x;
-    int j = blockIdx.y;
+    int j = j0 + blockIdx.y;
     if (i >= p1) return;
     const int mm = a.sv->map_size * a.sv->map_size;
     float f = -1.0f;
@@ -1374,11 +1374,15 @@ int rm_engine_radiosity_form_factors(rm_engine *e, int p0, int p1) {
     const int NP = e->n_patches;
     if (!e->d_ft) HIP_TRY(dev_alloc(&e->d_ft, (size_t)NP * NP));
     if (p0 == p1) return RM_OK;
-    if (NP > 65535) return fail(RM_ERR_LIMIT, "more than 65535 patches");
     RadArgs a = e->rad_args();
-    dim3 grid((p1 - p0 + 63) / 64, NP);
-    RM_LAUNCH(rad_form_kernel, e, grid, dim3(64), a, p0, p1);
-    HIP_TRY(hipGetLastError());
+    // sources go into the grid's y dimension, 65535 at most per launch (RM_RAD_CHUNK: test hook)
+    int chunk = 65535;
+    if (const char *c = getenv("RM_RAD_CHUNK")) chunk = std::max(1, std::min(65535, atoi(c)));
+    for (int j0 = 0; j0 < NP; j0 += chunk) {
+        dim3 grid((p1 - p0 + 63) / 64, std::min(chunk, NP - j0));
+        RM_LAUNCH(rad_form_kernel, e, grid, dim3(64), a, p0, p1, j0);
+        HIP_TRY(hipGetLastError());
+    }
     return RM_OK;
 }
 

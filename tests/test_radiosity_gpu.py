@@ -29,6 +29,34 @@ def test_lightmaps_match_oracle(scene, oracle_lightmaps, bounces):
     assert np.array_equal((got == 0).all(-1), (ref == 0).all(-1))
 
 
+def test_form_factor_launch_in_chunks(scene, oracle_lightmaps, monkeypatch):
+    """Sources beyond one launch's grid are taken in chunks (more than 65535 patches need it); a
+    tiny chunk size exercises the same code on the default maps."""
+    from raymarching_amd import Engine
+
+    lm, _ = oracle_lightmaps
+    monkeypatch.setenv("RM_RAD_CHUNK", "100")
+    e = Engine(scene, 64, 64)
+    e.compute_lightmaps(4)
+    got = np.stack([e.get_lightmap(i) for i in range(e.n_objects)])
+    e.close()
+    assert np.array_equal(got.view(np.uint32), lm[4].view(np.uint32))
+
+
+def test_large_maps_run(scene):
+    """MAP_SIZE 32 (8192 patches, 67 M form factors): finite, non-negative, and the same luxels
+    empty as geometry dictates.  (The CPU oracle would need hours at this size.)"""
+    from raymarching_amd import Engine
+
+    e = Engine(scene, 64, 64, map_size=32)
+    e.compute_lightmaps(4)
+    got = np.stack([e.get_lightmap(i) for i in range(e.n_objects)])
+    e.close()
+    assert got.shape == (8, 32, 32, 3)
+    assert np.isfinite(got).all() and (got >= 0).all()
+    assert (got.reshape(8, -1).max(axis=1) > 0).all()
+
+
 def test_sharded_bounces_equal_whole(scene):
     """Patch-sharded precompute (two halves, then an explicit exchange) equals the one-call result."""
     import torch
