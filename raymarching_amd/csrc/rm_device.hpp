@@ -36,7 +36,7 @@ RM_DEV unsigned *diag_kinds() {
 RM_DEV void diag_iter(bool active, int kind = 0) {
     unsigned *m = diag_mem();
     m[threadIdx.x] += active ? 1u : 0u;
-    if (threadIdx.x == 0) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) == threadIdx.x) {
         m[64] += 1u;
         diag_kinds()[kind] += 1u;
     }
@@ -53,7 +53,7 @@ RM_DEV unsigned *diag_laps() {
 RM_DEV void diag_lap(int k) {
     unsigned *t = diag_laps();
     const unsigned now = (unsigned)__builtin_readcyclecounter();
-    if (threadIdx.x == 0) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) == threadIdx.x) {  // the first lane still running
         t[2 + k] += now - t[0];
         t[0] = (unsigned)__builtin_readcyclecounter();
     }
@@ -70,6 +70,10 @@ RM_DEV void diag_lap(int) {}
 #define DG_REFLECT 0
 #define DG_PACK 0
 #endif
+
+// Wave votes on a predicate that already lives in a lane mask: no detour through a vector register.
+RM_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+RM_DEV bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0; }
 
 struct V3 {
     float x, y, z;
@@ -154,7 +158,7 @@ RM_DEV float smooth_min(float a, float b, float k) {
 RM_DEV float sqrt_rn(float x) {
     // One scalar branch for the whole wave: the special inputs practically never
     // occur, and a per-lane branch would cost more mask bookkeeping than it saves.
-    if (__all(x >= 0x1p-96f && x < __builtin_inff())) {
+    if (wave_all(x >= 0x1p-96f && x < __builtin_inff())) {
         float s = __builtin_amdgcn_sqrtf(x);
         float sd = __int_as_float(__float_as_int(s) - 1);
         float su = __int_as_float(__float_as_int(s) + 1);
@@ -560,7 +564,7 @@ RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, in
         pos.y = go ? p2.y : pos.y;
         pos.z = go ? p2.z : pos.z;
         active = go && (t2 < MAX_MARCH_DISTANCE);
-    } while (__any(active));
+    } while (wave_any(active));
     diag_lap(DG_MARCH_LOOP);
     const int idx = hit ? closest_index(sc, pos, d_hit, ign) : -1;
     diag_lap(DG_CLOSEST);
@@ -573,7 +577,7 @@ RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, in
 template <class SC>
 RM_DEV int march(const SC &sc, V3 &pos, V3 dir, int ignore, int cap, int &steps, bool &capped) {
     const int u = __builtin_amdgcn_readfirstlane(ignore);
-    if (__all(ignore == u)) {
+    if (wave_all(ignore == u)) {
         if (u < 0) return march_with(sc, pos, dir, NoIgnore{}, cap, steps, capped);
         return march_with(sc, pos, dir, UniformIgnore{u}, cap, steps, capped);
     }
@@ -610,7 +614,7 @@ RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float lig
         pos.y = active ? p2.y : pos.y;
         pos.z = active ? p2.z : pos.z;
         active = active && !(d < SMALL_DISTANCE || t2 > light_dist);
-        if (!__any(active)) break;
+        if (!wave_any(active)) break;
     }
     return rs_clamp(shade, 0.0f, 1.0f);
 }
@@ -618,7 +622,7 @@ RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float lig
 template <class SC>
 RM_DEV float smooth_shadow_march(const SC &sc, V3 pos, V3 dir, int ignore, float light_dist, float k) {
     const int u = __builtin_amdgcn_readfirstlane(ignore);
-    if (__all(ignore == u)) return shadow_with(sc, pos, dir, UniformIgnore{u}, light_dist, k);
+    if (wave_all(ignore == u)) return shadow_with(sc, pos, dir, UniformIgnore{u}, light_dist, k);
     return shadow_with(sc, pos, dir, LaneIgnore{ignore}, light_dist, k);
 }
 

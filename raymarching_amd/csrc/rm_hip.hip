@@ -102,6 +102,22 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderArgs 
         if (threadIdx.x == 0) px = (unsigned)diag_t0;
         if (threadIdx.x == 1) px = (unsigned)t1;
         if (threadIdx.x == 2) px = hw;
+#ifdef RM_DIAG
+        // with the iteration counters also built in: loop iterations of the wave, of its busiest
+        // lane, summed over lanes, and the number of marches
+        __syncthreads();
+        unsigned mx = 0, sum = 0;
+        for (int i = 0; i < 64; i++) {
+            mx = max(mx, diag_mem()[i]);
+            sum += diag_mem()[i];
+        }
+        if (threadIdx.x == 3) px = diag_mem()[64];
+        if (threadIdx.x == 4) px = mx;
+        if (threadIdx.x == 5) px = sum;
+        if (threadIdx.x == 6) px = diag_kinds()[5];
+        if (threadIdx.x >= 8 && threadIdx.x < 8 + DG_SECTIONS) px = diag_laps()[2 + threadIdx.x - 8];  // cycles per section
+        if (threadIdx.x >= 16 && threadIdx.x < 24) px = diag_kinds()[threadIdx.x - 16];
+#endif
     }
 #endif
     *reinterpret_cast<unsigned *>(a.out + (size_t)out_row * a.pitch + (size_t)x * 4) = px;

@@ -14,7 +14,17 @@ from raymarching_amd.engine import Engine
 W, H = int(os.environ.get("RM_W", 3840)), int(os.environ.get("RM_H", 2160))
 e = Engine(default_scene(), W, H)
 e.compute_lightmaps(4)
-for _ in range(3):
+only = os.environ.get("RM_ONLY_STRIP")  # render just this 8-row strip: every wave alone on its SIMD
+if only is not None:
+    r0 = int(only) * 8
+    buf = torch.zeros((8, W, 4), dtype=torch.uint8, device="cuda")
+    e.input(0, 0, (0, 0, 0), 0)
+    for _ in range(2):
+        e.render_rows_device(buf.data_ptr(), r0, r0 + 8)
+    e.synchronize()
+    img = buf.cpu().numpy()
+    H = 8
+else:
     img = e.render(None, 0, 0, (0, 0, 0), 0)
 px = img.view(np.uint32).reshape(H, W)
 t0 = px[0::8, 0::8].astype(np.int64)
@@ -31,5 +41,23 @@ order = np.argsort(end.ravel())[-8:]
 for i in order:
     ty, tx = divmod(int(i), W // 8)
     print(f"  late wave: tile ({tx},{ty}) start {start.ravel()[i]:.1f} us, lifetime {dur.ravel()[i]:.1f} us")
+if os.environ.get("RM_DIAG_BOTH"):
+    it = px[0::8, 3::8].astype(np.int64).ravel()
+    busiest = px[0::8, 4::8].astype(np.int64).ravel()
+    lanes = px[0::8, 5::8].astype(np.int64).ravel()
+    marches = px[0::8, 6::8].astype(np.int64).ravel()
+    for i in np.argsort(dur.ravel())[-8:]:
+        ty, tx = divmod(int(i), W // 8)
+        print(f"  long wave: tile ({tx},{ty}) {dur.ravel()[i]:.1f} us: {it[i]} loop iterations, busiest lane {busiest[i]}, "
+              f"mean lane {lanes[i] / 64:.0f}, {marches[i]} marches")
+    names = ["setup", "march loops", "closest", "shade", "shadow", "reflect bookkeeping", "pack"]
+    for i in np.argsort(dur.ravel())[-3:]:
+        ty, tx = divmod(int(i), W // 8)
+        laps = [int(px[ty * 8 + 1, tx * 8 + k]) for k in range(7)]  # lanes 8..14 are row 1 of the tile
+        kinds = [int(px[ty * 8 + 2, tx * 8 + k]) for k in range(8)]  # lanes 16..23 are row 2 of the tile
+        print(f"  tile ({tx},{ty}): cycles " + ", ".join(f"{n} {c}" for n, c in zip(names, laps)) + f"; total {sum(laps)}")
+        print(f"     march iterations {kinds[1]}, shadow iterations {kinds[2]}, sphere evaluations {kinds[3]}, penumbra divisions {kinds[4]}, marches {kinds[5]}")
+    heavy = dur.ravel() > np.percentile(dur, 99)
+    print(f"  slowest 1 % of waves: iterations {it[heavy].mean():.0f}, busiest lane {busiest[heavy].mean():.0f}, mean lane {lanes[heavy].mean() / 64:.0f}")
 np.save("gpurun_out/diag_time_dur.npy", dur.astype(np.float32))
 np.save("gpurun_out/diag_time_start.npy", start.astype(np.float32))
