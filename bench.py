@@ -38,6 +38,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the CPU baseline leg")
     ap.add_argument("--no-overlap", action="store_true", help="wait for each frame's all-gather before the next render")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="1 = frames one after the other; 2 = consecutive frames on two streams, so that the long-running "
+                         "tiles at the end of one frame overlap the start of the next (default: 1 on one GPU, 2 on several)")
     ap.add_argument("--workload", choices=["render", "radiosity", "stress"], default="render",
                     help="render: the headline frame benchmark; radiosity: Engine::compute_lightmaps, patch-sharded; "
                     "stress: 256 mixed primitives with smooth unions at 7680x4320, march cap 1024")
@@ -239,11 +242,19 @@ def main():
     bands = [torch.zeros((band_h, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
     frames = [torch.zeros((world * band_h, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
     final = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)] if interleaved else None
-    fx_src = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") if args.fxaa else None
+    fx_srcs = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)] if args.fxaa else None
 
     kernel_events = []
+    in_flight = args.frames_in_flight or (2 if world > 1 else 1)
+    if args.no_overlap:
+        in_flight = 1
+    # every frame of parity b is rendered, gathered and put in order on streams[b]
+    streams = [stream] + [torch.cuda.Stream() for _ in range(in_flight - 1)]
 
     def render_band(buf, timed):
+        fx_src = fx_srcs[0 if buf is bands[0] else 1] if args.fxaa else None  # one per frame in flight
+        stream = torch.cuda.current_stream()
+        eng.set_stream(stream.cuda_stream)
         if timed:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev1 = torch.cuda.Event(enable_timing=True)
@@ -292,19 +303,43 @@ def main():
             final[b].copy_(deinterleave_strips(frames[b], world, strips_per_rank, W, H))
 
     def run(steps, timed):
-        pending = None
+        if in_flight == 1:
+            pending = None
+            for s in range(steps):
+                b = s & 1
+                render_band(bands[b], timed)
+                if world > 1:
+                    if pending is not None:
+                        finish(pending)
+                    pending = (start_gather(frames[b].view(-1), bands[b].view(-1)), b)
+                    if args.no_overlap:
+                        finish(pending)
+                        pending = None
+            if pending is not None:
+                finish(pending)
+            return
+        # Two frames in flight: frame s lives on streams[s & 1] from its render to the re-ordering of
+        # its gathered strips, so the render of frame s+1 runs beside the tail of frame s.  Buffers of
+        # parity b are reused by frame s+2 on the same stream, after frame s has been finished there.
+        pending = [None, None]
+        for st in streams:
+            st.wait_stream(stream)
         for s in range(steps):
             b = s & 1
-            render_band(bands[b], timed)
-            if world > 1:
-                if pending is not None:
-                    finish(pending)
-                pending = (start_gather(frames[b].view(-1), bands[b].view(-1)), b)
-                if args.no_overlap:
-                    finish(pending)
-                    pending = None
-        if pending is not None:
-            finish(pending)
+            with torch.cuda.stream(streams[b]):
+                if pending[b] is not None:
+                    finish(pending[b])
+                    pending[b] = None
+                render_band(bands[b], timed)
+                if world > 1:
+                    pending[b] = (start_gather(frames[b].view(-1), bands[b].view(-1)), b)
+        for b in ((steps & 1), 1 - (steps & 1)):  # older frame first
+            if pending[b] is not None:
+                with torch.cuda.stream(streams[b]):
+                    finish(pending[b])
+        for st in streams[1:]:
+            stream.wait_stream(st)
+        eng.set_stream(stream.cuda_stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -375,11 +410,19 @@ def main():
                 "ssaa": 4 if args.ssaa else 1,
                 "map_size": 8,
                 "overlap_gather": world > 1 and not args.no_overlap,
+                "frames_in_flight": in_flight,
             },
             "roofline": roofline,
             "cap_hits": stats,
         }
-        if not args.no_cpu_baseline:
+        if world > 1 and not args.fxaa:
+            # the gathered frame against the same frame rendered whole on this GPU (bit for bit)
+            gathered = (final if interleaved else frames)[(args.steps - 1) & 1][:H]
+            local = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+            eng.render_rows_device(local.data_ptr(), 0, H)
+            torch.cuda.synchronize()
+            result["gathered_frame_equals_single_gpu_render"] = bool(torch.equal(gathered, local))
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N=1 only
             lightmaps = [eng.get_lightmap(i) for i in range(eng.n_objects)]
             base, cpu_rows = cpu_baseline(scene, lightmaps, W, H, args.cpu_seconds)
             result["cpu_baseline"] = base
