@@ -308,50 +308,43 @@ __global__ void rad_form_kernel(const RadArgs a, int p0, int p1, int j0, const G
     a.ft[(size_t)j * a.n_patches + i] = f;
 }
 
-// radiosity.rs:107-156 + 184-192 for one receiver: the ordered sum over sources.
-// The additions must run in source order (f32 addition does not associate), but
-// the loads need not wait for them: each thread fetches a batch of form factors
-// before it folds them in, which keeps enough loads in flight to stream FT.
-__global__ __launch_bounds__(64) void rad_bounce_kernel(const RadArgs a, int p0, int p1) {
-    const int i = p0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p1) return;
+// radiosity.rs:107-156 + 184-192 for 64 receivers per workgroup: the ordered sums over sources.
+// The additions of one receiver and channel must run in source order (f32 addition does not
+// associate), but fetching the form factors need not: all 256 threads stream a slab of FT
+// (kBounceChunk sources x 64 receivers, receiver-contiguous rows) and the matching emissive
+// values into LDS with many loads in flight, then three waves - one per colour channel - fold the
+// slab in order, one receiver per lane, and the next slab follows.  A pair that contributes nothing
+// (form factor -1) adds +0, which leaves a sum that started at +0 unchanged bit for bit.
+constexpr int kBounceChunk = 64;  // 64 x 64 floats of FT + 64 x 3 emissive floats: 17 KiB of LDS, eight workgroups per CU
+__global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0, int p1) {
+    __shared__ float slab[kBounceChunk][64];
+    __shared__ float em_s[kBounceChunk][3];
     const int NP = a.n_patches;
-    const float *__restrict__ ft = a.ft + i;
-    const float *__restrict__ em = a.emissive;
-    float ix = 0.0f, iy = 0.0f, iz = 0.0f;
-    constexpr int U = 16;
-    int j = 0;
-    for (; j + U <= NP; j += U) {
-        float f[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) f[u] = ft[(size_t)(j + u) * NP];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const float ex = em[3 * (j + u)], ey = em[3 * (j + u) + 1], ez = em[3 * (j + u) + 2];
-            if (f[u] != -1.0f) {
-                ix = ix + ex * f[u];
-                iy = iy + ey * f[u];
-                iz = iz + ez * f[u];
+    const int i0 = p0 + blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;  // part: row phase when loading, channel when summing
+    const int i = i0 + lane;
+    const bool valid = i < p1;
+    float acc = 0.0f;
+    for (int j0 = 0; j0 < NP; j0 += kBounceChunk) {
+        const int rows = min(kBounceChunk, NP - j0);
+        if (valid)
+            for (int jj = part; jj < rows; jj += 4) slab[jj][lane] = a.ft[(size_t)(j0 + jj) * NP + i];
+        for (int t = threadIdx.x; t < rows * 3; t += 256) em_s[t / 3][t % 3] = a.emissive[3 * j0 + t];
+        __syncthreads();
+        if (part < 3 && valid) {
+            for (int jj = 0; jj < rows; jj++) {
+                const float f = slab[jj][lane];
+                const float term = em_s[jj][part] * f;
+                acc = acc + (f != -1.0f ? term : 0.0f);
             }
         }
+        __syncthreads();
     }
-    for (; j < NP; j++) {
-        const float f = ft[(size_t)j * NP];
-        if (f != -1.0f) {
-            ix = ix + em[3 * j] * f;
-            iy = iy + em[3 * j + 1] * f;
-            iz = iz + em[3 * j + 2] * f;
-        }
+    if (part < 3 && valid) {
+        const float incident = acc / 3.14159265358979323846f;
+        a.lightmaps[3 * i + part] = a.lightmaps[3 * i + part] + incident;
+        a.emissive_next[3 * i + part] = incident * a.col[3 * i + part];
     }
-    V3 incident = v3(ix, iy, iz) / 3.14159265358979323846f;
-    V3 col = v3(a.col[3 * i], a.col[3 * i + 1], a.col[3 * i + 2]);
-    a.lightmaps[3 * i] = a.lightmaps[3 * i] + incident.x;
-    a.lightmaps[3 * i + 1] = a.lightmaps[3 * i + 1] + incident.y;
-    a.lightmaps[3 * i + 2] = a.lightmaps[3 * i + 2] + incident.z;
-    V3 ne = emul(incident, col);
-    a.emissive_next[3 * i] = ne.x;
-    a.emissive_next[3 * i + 1] = ne.y;
-    a.emissive_next[3 * i + 2] = ne.z;
 }
 
 // ---- FXAA (fxaa.txt:1-135, out of place) -------------------------------------
@@ -1411,7 +1404,7 @@ int rm_engine_radiosity_bounce(rm_engine *e, int p0, int p1) {
     if (int rc_ = sync_view(e)) return rc_;
     RadArgs a = e->rad_args();
     dim3 grid((p1 - p0 + 63) / 64);
-    hipLaunchKernelGGL(rad_bounce_kernel, grid, dim3(64), 0, e->stream, a, p0, p1);
+    hipLaunchKernelGGL(rad_bounce_kernel, grid, dim3(256), 0, e->stream, a, p0, p1);
     HIP_TRY(hipGetLastError());
     return RM_OK;
 }
