@@ -195,6 +195,9 @@ class Engine {
     // engine.rs:95-108 (commented out there): four rays per pixel
     void set_ssaa(bool on) { check(rm_engine_set_ssaa(handle_, on ? 4 : 1), "set_ssaa"); }
 
+    // objects.rs:142-149 (commented out there): four-point normals
+    void set_tetrahedral_normals(bool on) { check(rm_engine_set_tetrahedral_normals(handle_, on ? 1 : 0), "set_tetrahedral_normals"); }
+
     Vec3 camera_position() const {
         Vec3 p;
         check(rm_engine_get_camera(handle_, &p.x), "get_camera");

@@ -217,6 +217,11 @@ int rm_engine_probe_shade(rm_engine *engine, int n, const int32_t *object, const
  * samples = 1 (the default) is the reference's live path.  Applies to every render entry point. */
 int rm_engine_set_ssaa(rm_engine *engine, int samples);
 
+/* Surface normals, objects.rs:135-149: on = 0 (default) takes the central differences of the live
+ * code (step 0.0001); on = 1 the four-point tetrahedral form the reference carries commented out
+ * (step 0.0015).  Applies to shading and to the normals of the lightmap precompute. */
+int rm_engine_set_tetrahedral_normals(rm_engine *engine, int on);
+
 /* Optional divergence cap on march iterations (0 = none; the loop of ray.rs:19
  * ends by itself after at most 50/0.001 steps).  Cut marches are counted. */
 int rm_engine_set_march_cap(rm_engine *engine, int max_steps);

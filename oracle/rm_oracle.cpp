@@ -324,6 +324,7 @@ struct EngineObject {
     Colour colour_const;
     Lightmap lightmap;
     bool has_lightmap = true;
+    bool tetra_normals = false;  // EXTENSION switch: the commented-out four-point normal of objects.rs:142-149
     int type = T_SPHERE;
 
     explicit EngineObject(int map_size) : lightmap(map_size) {}
@@ -434,6 +435,15 @@ struct EngineObject {
             CNT(normals_gplane, 1);
         else
             CNT(normals_plane, 1);
+        if (tetra_normals) {
+            // objects.rs:18-24 and 142-149 (commented out in the reference)
+            const float TETRA_STEP = 0.0015f;
+            const Vec3 STEP_A(TETRA_STEP, -TETRA_STEP, -TETRA_STEP), STEP_B(-TETRA_STEP, -TETRA_STEP, TETRA_STEP);
+            const Vec3 STEP_C(-TETRA_STEP, TETRA_STEP, -TETRA_STEP), STEP_D(TETRA_STEP, TETRA_STEP, TETRA_STEP);
+            Vec3 norm = STEP_A * sdf(position + STEP_A) + STEP_B * sdf(position + STEP_B) + STEP_C * sdf(position + STEP_C) +
+                        STEP_D * sdf(position + STEP_D);
+            return norm.normalized();
+        }
         float gx = sdf(position + X_STEP) - sdf(position - X_STEP);
         float gy = sdf(position + Y_STEP) - sdf(position - Y_STEP);
         float gz = sdf(position + Z_STEP) - sdf(position - Z_STEP);
@@ -1207,6 +1217,9 @@ int orc_add_box(void *h, const float *pos, const float *half, const float *mat, 
 }
 void orc_set_smooth_union(void *h, float k) { static_cast<Engine *>(h)->smooth_k = k; }
 void orc_set_ssaa(void *h, int samples) { static_cast<Engine *>(h)->ssaa = samples; }
+void orc_set_tetrahedral_normals(void *h, int on) {
+    for (auto &o : static_cast<Engine *>(h)->objects) o->tetra_normals = on != 0;
+}
 float orc_kat_smooth_min(float a, float b, float k) { return smooth_min(a, b, k); }
 void orc_set_light(void *h, const float *pos, float intensity) {
     Engine *e = static_cast<Engine *>(h);

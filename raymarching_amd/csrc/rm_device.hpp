@@ -626,10 +626,21 @@ RM_DEV float smooth_shadow_march(const SC &sc, V3 pos, V3 dir, int ignore, float
     return shadow_with(sc, pos, dir, LaneIgnore{ignore}, light_dist, k);
 }
 
-// objects.rs:135-141 for a per-lane object.  The six evaluations sit inside one dispatch on the
-// type, so a wave runs them only for the types its lanes hold.
+// objects.rs:135-141 for a per-lane object.  The evaluations sit inside one dispatch on the type,
+// so a wave runs them only for the types its lanes hold.  `tetra` (the same in every lane) selects
+// the four-point form the reference carries commented out (objects.rs:18-24, 142-149): the sum of
+// step vector times distance over the corners of a tetrahedron of half edge 0.0015.
+constexpr float TETRA_STEP = 0.0015f;
 template <int TYPE>
-RM_DEV V3 central_differences(const Geom &g, V3 p) {
+RM_DEV V3 sdf_gradient(const Geom &g, V3 p, bool tetra) {
+    if (tetra) {
+        const float T = TETRA_STEP;
+        const float sa = sdf_eval(TYPE, g, v3(p.x + T, p.y + -T, p.z + -T));
+        const float sb = sdf_eval(TYPE, g, v3(p.x + -T, p.y + -T, p.z + T));
+        const float sc = sdf_eval(TYPE, g, v3(p.x + -T, p.y + T, p.z + -T));
+        const float sd = sdf_eval(TYPE, g, v3(p.x + T, p.y + T, p.z + T));
+        return ((v3(T, -T, -T) * sa + v3(-T, -T, T) * sb) + v3(-T, T, -T) * sc) + v3(T, T, T) * sd;
+    }
     float gx = sdf_eval(TYPE, g, v3(p.x + STEP_SIZE, p.y + 0.0f, p.z + 0.0f)) -
                sdf_eval(TYPE, g, v3(p.x - STEP_SIZE, p.y - 0.0f, p.z - 0.0f));
     float gy = sdf_eval(TYPE, g, v3(p.x + 0.0f, p.y + STEP_SIZE, p.z + 0.0f)) -
@@ -638,15 +649,15 @@ RM_DEV V3 central_differences(const Geom &g, V3 p) {
                sdf_eval(TYPE, g, v3(p.x - 0.0f, p.y - 0.0f, p.z - STEP_SIZE));
     return v3(gx, gy, gz);
 }
-RM_DEV V3 calculate_normal(int type, const Geom &g, V3 p) {
+RM_DEV V3 calculate_normal(int type, const Geom &g, V3 p, bool tetra) {
     V3 grad;
     switch (type) {
-        case T_SPHERE: grad = central_differences<T_SPHERE>(g, p); break;
-        case T_XPLANE: grad = central_differences<T_XPLANE>(g, p); break;
-        case T_YPLANE: grad = central_differences<T_YPLANE>(g, p); break;
-        case T_ZPLANE: grad = central_differences<T_ZPLANE>(g, p); break;
-        case T_PLANE: grad = central_differences<T_PLANE>(g, p); break;
-        default: grad = central_differences<T_BOX>(g, p); break;
+        case T_SPHERE: grad = sdf_gradient<T_SPHERE>(g, p, tetra); break;
+        case T_XPLANE: grad = sdf_gradient<T_XPLANE>(g, p, tetra); break;
+        case T_YPLANE: grad = sdf_gradient<T_YPLANE>(g, p, tetra); break;
+        case T_ZPLANE: grad = sdf_gradient<T_ZPLANE>(g, p, tetra); break;
+        case T_PLANE: grad = sdf_gradient<T_PLANE>(g, p, tetra); break;
+        default: grad = sdf_gradient<T_BOX>(g, p, tetra); break;
     }
     return normalized(grad);
 }
@@ -819,7 +830,7 @@ RM_DEV ShadeResult shade_local(const SC &sc, const SceneView &sv, int idx, V3 po
     const Geom g = sv.geom[idx];
     ShadeResult out;
     V3 oc = (RM_ABL & 64) ? v3(sr.cr, sr.cg, sr.cb) : object_colour(sv, sr, g, pos);
-    V3 n = (RM_ABL & 32) ? v3(0.0f, 1.0f, 0.0f) : calculate_normal(sr.type, g, pos);
+    V3 n = (RM_ABL & 32) ? v3(0.0f, 1.0f, 0.0f) : calculate_normal(sr.type, g, pos, sv.tetra_normals != 0);
 
     V3 ambient;
     if ((RM_ABL & 4) || sr.lm_slot < 0)

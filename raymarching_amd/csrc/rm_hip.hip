@@ -232,7 +232,7 @@ __global__ void rad_cloud_kernel(const RadArgs a) {
     const ShadeRec sr = a.sv->shade[obj];
     const Geom g = a.sv->geom[obj];
     V3 c = object_colour(*a.sv, sr, g, pos);
-    V3 n = calculate_normal(sr.type, g, pos);
+    V3 n = calculate_normal(sr.type, g, pos, a.sv->tetra_normals != 0);
     a.col[3 * p] = c.x;
     a.col[3 * p + 1] = c.y;
     a.col[3 * p + 2] = c.z;
@@ -262,7 +262,7 @@ __global__ void rad_direct_kernel(const RadArgs a, const G grp) {
     march(acc_of(grp), rp, to_light, obj, 0, steps, capped);
     V3 em = v3(0.0f, 0.0f, 0.0f), lm = v3(0.0f, 0.0f, 0.0f);
     if (!(mag(rp - origin) < (dist + 3.0f * SMALL_DISTANCE))) {
-        V3 n = calculate_normal(sr.type, g, origin);
+        V3 n = calculate_normal(sr.type, g, origin, a.sv->tetra_normals != 0);
         float diffuse = rs_max(dot(n, to_light), 0.0f) * a.sv->intensity / (dist * dist);
         em = colour * (diffuse + sr.emissive);
         lm = colour * sr.emissive;
@@ -477,6 +477,7 @@ struct rm_engine {
     Pose pose;
     int march_cap = 0;
     bool ssaa = false;  // four rays per pixel (engine.rs:95-108)
+    bool tetra_normals = false;  // objects.rs:142-149
     size_t grid_entries = 0;  // list entries of the spatial index (0 = none)
 
     // device-resident scene
@@ -533,6 +534,7 @@ struct rm_engine {
         const float sky8[3] = {135.0f, 206.0f, 235.0f};
         for (int i = 0; i < 3; i++) sv.sky[i] = (sky8[i] / 255.0f) * (sky8[i] / 255.0f);
         sv.march_cap = march_cap;
+        sv.tetra_normals = tetra_normals ? 1 : 0;
         sv.stats = d_stats;
         return sv;
     }
@@ -1472,6 +1474,13 @@ int rm_engine_set_lightmap(rm_engine *e, int object, const float *values) {
 int rm_engine_set_ssaa(rm_engine *e, int samples) {
     if (!e || (samples != 1 && samples != 4)) return fail(RM_ERR_INVALID, "samples must be 1 or 4");
     e->ssaa = samples == 4;
+    return RM_OK;
+}
+
+int rm_engine_set_tetrahedral_normals(rm_engine *e, int on) {
+    if (!e) return fail(RM_ERR_INVALID, "NULL engine");
+    e->tetra_normals = on != 0;
+    e->view_dirty = true;
     return RM_OK;
 }
 

@@ -122,6 +122,7 @@ struct SceneView {
     float intensity;
     float sky[3];
     int march_cap;  // 0 = none
+    int tetra_normals;  // 1 = the four-point normal of objects.rs:142-149 (commented out there)
     unsigned long long *stats;
 };
 

@@ -218,6 +218,10 @@ class Engine:
         """engine.rs:95-108: 4 = four rays per pixel, averaged; 1 = off."""
         _lib.check(self.lib.rm_engine_set_ssaa(self.handle, samples), "rm_engine_set_ssaa")
 
+    def set_tetrahedral_normals(self, on):
+        """objects.rs:142-149: the four-point normal instead of central differences."""
+        _lib.check(self.lib.rm_engine_set_tetrahedral_normals(self.handle, 1 if on else 0), "rm_engine_set_tetrahedral_normals")
+
     def set_march_cap(self, max_steps):
         _lib.check(self.lib.rm_engine_set_march_cap(self.handle, max_steps), "rm_engine_set_march_cap")
 

@@ -52,6 +52,7 @@ def load(counting=False):
     lib.orc_add_box.argtypes = [c_void_p, _F, _F, _F, _F]
     lib.orc_set_smooth_union.argtypes = [c_void_p, c_float]
     lib.orc_set_ssaa.argtypes = [c_void_p, c_int]
+    lib.orc_set_tetrahedral_normals.argtypes = [c_void_p, c_int]
     lib.orc_kat_smooth_min.restype = c_float
     lib.orc_kat_smooth_min.argtypes = [c_float, c_float, c_float]
     lib.orc_set_light.argtypes = [c_void_p, _F, c_float]
@@ -140,6 +141,9 @@ class OracleEngine:
 
     def set_ssaa(self, samples):
         self.lib.orc_set_ssaa(self.handle, samples)
+
+    def set_tetrahedral_normals(self, on):
+        self.lib.orc_set_tetrahedral_normals(self.handle, 1 if on else 0)
 
     def set_light(self, pos, intensity):
         self.lib.orc_set_light(self.handle, _fa(pos), intensity)

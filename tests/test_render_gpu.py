@@ -197,6 +197,26 @@ def test_supersampled_frame(scene, oracle_lightmaps):
     eng.close()
 
 
+def test_tetrahedral_normals(scene):
+    """The four-point normal the reference carries commented out (objects.rs:142-149), through the
+    lightmap precompute (cloud and direct-light normals) and a frame."""
+    from raymarching_amd import Engine
+
+    w, h = 240, 180
+    ora = make_oracle(scene)
+    ora.set_tetrahedral_normals(True)
+    ora.compute_lightmaps(2)
+    eng = Engine(scene, w, h)
+    eng.set_tetrahedral_normals(True)
+    eng.compute_lightmaps(2)
+    for i in range(eng.n_objects):
+        assert np.array_equal(eng.get_lightmap(i).view(np.uint32), ora.get_lightmap(i).view(np.uint32)), i
+    pose = (-90, 40, (0.2, 0.0, 0.4), 1)
+    mx, exact = assert_frames_match(eng.render(None, *pose), ora.render(w, h, *pose), "tetrahedral normals")
+    print(f"tetrahedral normals: max|d|={mx} exact={exact:.5%}")
+    eng.close()
+
+
 def test_frame_sequence_with_recorded_input(scene, oracle_lightmaps):
     """A recorded input trace (mouse look, WASD movement, scroll zoom; main.rs:105-138) played
     through the pipelined rm_engine_render_async path: every frame and the final camera match the
