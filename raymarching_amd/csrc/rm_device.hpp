@@ -207,28 +207,46 @@ struct SceneSmallAcc {
     RM_DEV float smooth_k() const { return 0.0f; }
 };
 
+// Scene geometry does not change while a kernel runs.  Reading it through the constant address
+// space tells the compiler so: loads at wave-uniform addresses become scalar loads (one fetch per
+// wave, into scalar registers) even where the kernel's own atomics and stores would otherwise make
+// it assume the data might have changed.
+typedef const __attribute__((address_space(4))) float *ConstFloats;
+typedef const __attribute__((address_space(4))) int *ConstInts;
+typedef float Float4 __attribute__((ext_vector_type(4)));  // 16-byte loads
+typedef int Int4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) Float4 *ConstFloat4s;
+typedef const __attribute__((address_space(4))) Int4 *ConstInt4s;
+RM_DEV ConstFloats constant(const float *p) { return (ConstFloats)p; }
+RM_DEV ConstInts constant(const int *p) { return (ConstInts)p; }
+
 struct SceneLargeAcc {
     const GroupedLarge &g;
     template <class F>
     RM_DEV void spheres(F &&f) const {
-        for (int i = 0; i < g.n_sph; i++) f(i, g.idx_sph[i], g.sph[4 * i], g.sph[4 * i + 1], g.sph[4 * i + 2], g.sph[4 * i + 3]);
+        ConstInts idx = constant(g.idx_sph);
+        ConstFloats s = constant(g.sph);
+        for (int i = 0; i < g.n_sph; i++) f(i, idx[i], s[4 * i], s[4 * i + 1], s[4 * i + 2], s[4 * i + 3]);
     }
     template <int AXIS, class F>
     RM_DEV void axis(F &&f) const {
         const int n = AXIS == 0 ? g.n_x : (AXIS == 1 ? g.n_y : g.n_z);
-        const int *idx = g.idx_ax[AXIS];
-        const float *a = g.ax[AXIS];
+        ConstInts idx = constant(g.idx_ax[AXIS]);
+        ConstFloats a = constant(g.ax[AXIS]);
         for (int i = 0; i < n; i++) f(idx[i], a[2 * i], a[2 * i + 1]);
     }
     template <class F>
     RM_DEV void planes(F &&f) const {
-        for (int i = 0; i < g.n_gp; i++) f(g.idx_gp[i], g.gp[4 * i], g.gp[4 * i + 1], g.gp[4 * i + 2], g.gp[4 * i + 3]);
+        ConstInts idx = constant(g.idx_gp);
+        ConstFloats gp = constant(g.gp);
+        for (int i = 0; i < g.n_gp; i++) f(idx[i], gp[4 * i], gp[4 * i + 1], gp[4 * i + 2], gp[4 * i + 3]);
     }
     template <class F>
     RM_DEV void boxes(F &&f) const {
+        ConstInts idx = constant(g.idx_box);
         for (int i = 0; i < g.n_box; i++) {
-            const float *b = g.box + 8 * i;
-            f(g.idx_box[i], v3(b[0], b[1], b[2]), v3(b[3], b[4], b[5]));
+            ConstFloats b = constant(g.box) + 8 * i;
+            f(idx[i], v3(b[0], b[1], b[2]), v3(b[3], b[4], b[5]));
         }
     }
     static constexpr bool kSmooth = true;
@@ -315,17 +333,20 @@ RM_DEV float box_sdf(V3 c, V3 h, V3 p) {
 // grid (or a NaN).
 struct CellLists {
     int s0, s1, b0, b1;
+    float reach;  // every primitive outside the lists is at least this far from p
 };
 RM_DEV CellLists grid_cell(const GridView &gv, V3 p) {
     const float fx = (p.x - gv.ox) * gv.inv_cell, fy = (p.y - gv.oy) * gv.inv_cell, fz = (p.z - gv.oz) * gv.inv_cell;
     const bool inside = fx >= 0.0f && fx < (float)gv.nx && fy >= 0.0f && fy < (float)gv.ny && fz >= 0.0f && fz < (float)gv.nz;
-    CellLists c = {0, 0, 0, 0};
+    CellLists c = {0, 0, 0, 0, gv.reach};
     if (inside) {
         const int cell = ((int)fz * gv.ny + (int)fy) * gv.nx + (int)fx;  // non-negative: truncation is floor
-        c.s0 = gv.sph_start[cell];
-        c.s1 = gv.sph_start[cell + 1];
-        c.b0 = gv.box_start[cell];
-        c.b1 = gv.box_start[cell + 1];
+        const Int4 rec = ((ConstInt4s)gv.cell)[cell];  // one 16-byte record: first sphere, first box, counts, reach
+        c.s0 = rec.x;
+        c.s1 = rec.x + (rec.z & 0xffff);
+        c.b0 = rec.y;
+        c.b1 = rec.y + ((unsigned)rec.z >> 16);
+        c.reach = __int_as_float(rec.w);
     }
     return c;
 }
@@ -349,7 +370,7 @@ template <class SC, class IGN>
 RM_DEV bool grid_fold(const SC &sc, V3 p, const IGN &ign, float &r, float k, bool blend) {
     const GridView &gv = sc.grid();
     const CellLists c = grid_cell(gv, p);
-    const float R = gv.reach;
+    const float R = c.reach;
     bool certain = r <= R - k;  // blend only
     float floor_before = rs_min(r, R);
     const float slack = 2.01f * k + 1e-4f;
@@ -366,18 +387,44 @@ RM_DEV bool grid_fold(const SC &sc, V3 p, const IGN &ign, float &r, float k, boo
             r = rs_min(r, s);
         }
     };
-    for (int e = c.s0; e < c.s1; e++) {
-        const float4 g = reinterpret_cast<const float4 *>(gv.sph_geom)[e];
-        const int oi = gv.sph_index[e];
-        const float s = sqrt_rn(mag_sqd(p - v3(g.x, g.y, g.z))) - g.w;
-        fold(ign.skip(oi) ? __builtin_inff() : ign.mask(oi, s));
+    // Entries are fetched four (boxes: two) at a time before any is used, so that a list costs one
+    // memory round trip per group instead of one per entry; they are folded one by one, in order.
+    const ConstFloat4s sph_geom = (ConstFloat4s)gv.sph_geom, box_geom = (ConstFloat4s)gv.box_geom;
+    const ConstInts sph_index = constant(gv.sph_index), box_index = constant(gv.box_index);
+    for (int e = c.s0; e < c.s1; e += 4) {
+        Float4 g[4];
+        int oi[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int ee = min(e + u, c.s1 - 1);
+            g[u] = sph_geom[ee];
+            oi[u] = sph_index[ee];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (e + u < c.s1) {
+                const float s = sqrt_rn(mag_sqd(p - v3(g[u].x, g[u].y, g[u].z))) - g[u].w;
+                fold(ign.skip(oi[u]) ? __builtin_inff() : ign.mask(oi[u], s));
+            }
+        }
     }
-    for (int e = c.b0; e < c.b1; e++) {
-        const float4 g0 = reinterpret_cast<const float4 *>(gv.box_geom)[2 * e];
-        const float4 g1 = reinterpret_cast<const float4 *>(gv.box_geom)[2 * e + 1];
-        const int oi = gv.box_index[e];
-        const float s = box_sdf(v3(g0.x, g0.y, g0.z), v3(g0.w, g1.x, g1.y), p);
-        fold(ign.skip(oi) ? __builtin_inff() : ign.mask(oi, s));
+    for (int e = c.b0; e < c.b1; e += 2) {
+        Float4 g0[2], g1[2];
+        int oi[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int ee = min(e + u, c.b1 - 1);
+            g0[u] = box_geom[2 * ee];
+            g1[u] = box_geom[2 * ee + 1];
+            oi[u] = box_index[ee];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (e + u < c.b1) {
+                const float s = box_sdf(v3(g0[u].x, g0[u].y, g0[u].z), v3(g0[u].w, g1[u].x, g1[u].y), p);
+                fold(ign.skip(oi[u]) ? __builtin_inff() : ign.mask(oi[u], s));
+            }
+        }
     }
     return blend ? certain : (r <= R);
 }
@@ -425,7 +472,9 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, bool active, SphereBo
         if (sc.grid().cells > 0) {
             if (!active) return d;
             float r = d;
+            diag_event(6);
             if (grid_fold(sc, p, ign, r, k, blend)) return r;
+            diag_event(7);
             // not certain from the cell's lists alone: the full walk below settles it
         }
     }
@@ -496,7 +545,7 @@ RM_DEV int closest_index(const SC &sc, V3 p, float, const IGN &ign) {
                 const int oi = gv.box_index[e];
                 if (!ign.skip(oi)) take(oi, box_sdf(v3(g0.x, g0.y, g0.z), v3(g0.w, g1.x, g1.y), p));
             }
-            if (best < gv.reach) return bi;
+            if (best < c.reach) return bi;
         }
     }
     sc.spheres([&](int, int oi, float cx, float cy, float cz, float r) {

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -467,6 +468,8 @@ struct rm_scene {
 constexpr int kStatSlots = 32;
 constexpr int kGridMinPrimitives = 16;  // fewer bounded primitives than this: no spatial index
 constexpr int kGridMaxDim = 48;         // cells per axis at most
+constexpr int kGridMinList = 6;         // a cell lists at least this many primitives (its reach grows to admit them)
+constexpr int kGridMaxList = 48;        // and at most this many (its reach shrinks)
 
 struct rm_engine {
     int device = 0;
@@ -768,31 +771,40 @@ static int engine_upload(rm_engine *e) {
             const double ex[3] = {(double)bhi[0] - blo[0], (double)bhi[1] - blo[1], (double)bhi[2] - blo[2]};
             const double longest = std::max(ex[0], std::max(ex[1], ex[2]));
             if (finite && longest > 0.0) {
-                // mean spacing of the primitives; cells a quarter of it, reach 0.85 of it plus the blend width
-                // (the fastest of a sweep over both on the 250-primitive stress scenes: longer lists cost more
-                // than the full walks that shorter ones cause)
+                // Mean spacing of the primitives; cells a quarter of it, base reach 0.85 of it plus the
+                // blend width (the fastest of a sweep over both on the 250-primitive stress scenes: longer
+                // lists cost more than the full walks that shorter ones cause).  A cell with fewer than
+                // kGridMinList primitives within the base reach takes the reach that admits that many, so
+                // that open space far from everything still gets the few nearest primitives and a large
+                // reach instead of a full walk; kGridMaxList caps a list by lowering the cell's reach.
                 const double vol = std::max(ex[0], 0.05 * longest) * std::max(ex[1], 0.05 * longest) * std::max(ex[2], 0.05 * longest);
                 const double spacing = std::cbrt(vol / n_bounded);
-                const double reach_mul = getenv("RM_GRID_REACH") ? atof(getenv("RM_GRID_REACH")) : 0.85;  // tuning aid
+                const double reach_mul = getenv("RM_GRID_REACH") ? atof(getenv("RM_GRID_REACH")) : 0.85;  // tuning aids
                 const double cell_mul = getenv("RM_GRID_CELL") ? atof(getenv("RM_GRID_CELL")) : 0.25;
+                const int min_list = getenv("RM_GRID_MINLIST") ? atoi(getenv("RM_GRID_MINLIST")) : kGridMinList;
+                const int max_list = getenv("RM_GRID_MAXLIST") ? atoi(getenv("RM_GRID_MAXLIST")) : kGridMaxList;
                 const float reach = (float)(reach_mul * spacing + 2.0 * s.smooth_k);
+                // the grid spans the primitives and half their extent around them; beyond it every
+                // primitive is at least `apron` away
+                const float apron = fmaxf(reach, (float)(0.5 * longest));
                 float cell = (float)(cell_mul * spacing);
-                cell = fmaxf(cell, (float)((longest + 2.0 * reach) / kGridMaxDim));
-                const float scale = fmaxf(fmaxf(fabsf(blo[0]), fabsf(bhi[0])), fmaxf(fmaxf(fabsf(blo[1]), fabsf(bhi[1])), fmaxf(fabsf(blo[2]), fabsf(bhi[2])))) + reach;
+                cell = fmaxf(cell, (float)((longest + 2.0 * apron) / kGridMaxDim));
+                const float scale = fmaxf(fmaxf(fabsf(blo[0]), fabsf(bhi[0])), fmaxf(fmaxf(fabsf(blo[1]), fabsf(bhi[1])), fmaxf(fabsf(blo[2]), fabsf(bhi[2])))) + apron;
                 const float margin = 1e-3f + 1e-5f * scale;  // rounding of the cell lookup and of the distances
                 GridView gv;
                 memset(&gv, 0, sizeof(gv));
-                gv.ox = blo[0] - reach - margin;
-                gv.oy = blo[1] - reach - margin;
-                gv.oz = blo[2] - reach - margin;
+                gv.ox = blo[0] - apron - margin;
+                gv.oy = blo[1] - apron - margin;
+                gv.oz = blo[2] - apron - margin;
                 gv.inv_cell = 1.0f / cell;
-                gv.reach = reach;
-                gv.nx = std::max(1, (int)std::ceil((bhi[0] + reach + margin - gv.ox) / cell));
-                gv.ny = std::max(1, (int)std::ceil((bhi[1] + reach + margin - gv.oy) / cell));
-                gv.nz = std::max(1, (int)std::ceil((bhi[2] + reach + margin - gv.oz) / cell));
+                gv.reach = apron;
+                gv.nx = std::max(1, (int)std::ceil((bhi[0] + apron + margin - gv.ox) / cell));
+                gv.ny = std::max(1, (int)std::ceil((bhi[1] + apron + margin - gv.oy) / cell));
+                gv.nz = std::max(1, (int)std::ceil((bhi[2] + apron + margin - gv.oz) / cell));
                 gv.cells = gv.nx * gv.ny * gv.nz;
                 std::vector<int> s_start(gv.cells + 1, 0), b_start(gv.cells + 1, 0), s_index, b_index;
-                std::vector<float> s_geom, b_geom;
+                std::vector<float> s_geom, b_geom, cell_reach(gv.cells, 0.0f);
+                std::vector<float> lb(n_bounded), sorted(n_bounded);
                 const float origin[3] = {gv.ox, gv.oy, gv.oz};
                 for (int cz = 0; cz < gv.nz; cz++)
                     for (int cy = 0; cy < gv.ny; cy++)
@@ -805,46 +817,69 @@ static int engine_upload(rm_engine *e) {
                                 clo[a] = origin[a] + (float)ci[a] * cell - margin;
                                 chi[a] = origin[a] + (float)(ci[a] + 1) * cell + margin;
                             }
+                            // lower bound of every primitive's distance over the cell
                             for (int i = 0; i < n_bounded; i++) {
                                 const bool is_sphere = i < (int)gi_sph.size();
-                                double d2 = 0.0;  // squared distance between the cell and the primitive's bounds
+                                double d2 = 0.0;
                                 if (is_sphere) {
                                     const float *g = &g_sph[4 * i];
                                     for (int a = 0; a < 3; a++) {
                                         const double t = std::max(0.0, std::max((double)clo[a] - g[a], (double)g[a] - chi[a]));
                                         d2 += t * t;
                                     }
-                                    const double d = std::sqrt(d2) - fabs((double)g[3]);
-                                    if (d < (double)reach + margin) {
-                                        s_index.push_back(gi_sph[i]);
-                                        s_geom.insert(s_geom.end(), g, g + 4);
-                                    }
+                                    lb[i] = (float)(std::sqrt(d2) - fabs((double)g[3])) - margin;
                                 } else {
-                                    const int b = i - (int)gi_sph.size();
                                     for (int a = 0; a < 3; a++) {
                                         const double t = std::max(0.0, std::max((double)clo[a] - hi[3 * i + a], (double)lo[3 * i + a] - chi[a]));
                                         d2 += t * t;
                                     }
-                                    if (std::sqrt(d2) < (double)reach + margin) {
-                                        b_index.push_back(gi_box[b]);
-                                        b_geom.insert(b_geom.end(), &g_box[8 * b], &g_box[8 * b] + 8);
-                                    }
+                                    lb[i] = (float)std::sqrt(d2) - margin;
+                                }
+                            }
+                            // the cell's reach: every primitive with lb < r is listed, every other is >= r away
+                            sorted = lb;
+                            std::sort(sorted.begin(), sorted.end());
+                            float r = reach;
+                            const int want = std::min(min_list, n_bounded);
+                            if (want > 0 && !(sorted[want - 1] < r))
+                                r = want < n_bounded ? std::nextafter(sorted[want - 1], INFINITY) : INFINITY;
+                            if (n_bounded > max_list && sorted[max_list] < r) r = sorted[max_list];
+                            cell_reach[c] = r;
+                            for (int i = 0; i < n_bounded; i++) {
+                                if (!(lb[i] < r)) continue;
+                                if (i < (int)gi_sph.size()) {
+                                    s_index.push_back(gi_sph[i]);
+                                    s_geom.insert(s_geom.end(), &g_sph[4 * i], &g_sph[4 * i] + 4);
+                                } else {
+                                    const int b = i - (int)gi_sph.size();
+                                    b_index.push_back(gi_box[b]);
+                                    b_geom.insert(b_geom.end(), &g_box[8 * b], &g_box[8 * b] + 8);
                                 }
                             }
                             s_start[c + 1] = (int)s_index.size();
                             b_start[c + 1] = (int)b_index.size();
                         }
-                HIP_TRY(up_i(s_start, &gv.sph_start));
+                std::vector<int> cell_rec(4 * (size_t)gv.cells);
+                for (int c = 0; c < gv.cells; c++) {
+                    cell_rec[4 * c] = s_start[c];
+                    cell_rec[4 * c + 1] = b_start[c];
+                    cell_rec[4 * c + 2] = (s_start[c + 1] - s_start[c]) | ((b_start[c + 1] - b_start[c]) << 16);
+                    memcpy(&cell_rec[4 * c + 3], &cell_reach[c], sizeof(float));
+                }
+                HIP_TRY(up_i(cell_rec, &gv.cell));
                 HIP_TRY(up_f(s_geom, &gv.sph_geom));
                 HIP_TRY(up_i(s_index, &gv.sph_index));
-                HIP_TRY(up_i(b_start, &gv.box_start));
                 HIP_TRY(up_f(b_geom, &gv.box_geom));
                 HIP_TRY(up_i(b_index, &gv.box_index));
                 gl.grid = gv;
                 e->grid_entries = s_index.size() + b_index.size();
-                if (getenv("RM_VERBOSE"))
-                    fprintf(stderr, "rm: spatial index %d x %d x %d cells of %.3f, reach %.3f, %zu entries (%.1f per cell) for %d primitives\n",
-                            gv.nx, gv.ny, gv.nz, cell, reach, e->grid_entries, (double)e->grid_entries / gv.cells, n_bounded);
+                if (getenv("RM_VERBOSE")) {
+                    int longest_list = 0;
+                    for (int c = 0; c < gv.cells; c++)
+                        longest_list = std::max(longest_list, s_start[c + 1] - s_start[c] + b_start[c + 1] - b_start[c]);
+                    fprintf(stderr, "rm: spatial index %d x %d x %d cells of %.3f, base reach %.3f, apron %.3f, %zu entries (%.1f per cell, longest list %d) for %d primitives\n",
+                            gv.nx, gv.ny, gv.nz, cell, reach, apron, e->grid_entries, (double)e->grid_entries / gv.cells, longest_list, n_bounded);
+                }
             }
         }
     }
