@@ -139,6 +139,17 @@ def test_sdf_and_normals(lib):
     assert abs(out[0] - 1.0) < 1e-3 and abs(out[1]) < 1e-3 and abs(out[2]) < 1e-3
     lib.orc_kat_normal(e.handle, 3, F3(1.0, 1.0, 2.0), out)
     assert out[0] == 0.0 and out[1] == 0.0 and out[2] == -1.0
+    # the commented-out four-point form (objects.rs:18-24, 142-149).  For the plane z = 2, dir = -1:
+    # with s the distance at p and T = 0.0015, the corner distances are s+T (A), s-T (B), s+T (C),
+    # s-T (D); the z component is -T(s+T) + T(s-T) - T(s+T) + T(s-T) = -4T^2, x and y cancel up to
+    # the rounding of the four products: the normal is (0, 0, -1) to within 1e-6.
+    e.set_tetrahedral_normals(True)
+    lib.orc_kat_normal(e.handle, 3, F3(1.0, 1.0, 1.5), out)
+    assert abs(out[0]) < 1e-6 and abs(out[1]) < 1e-6 and abs(out[2] + 1.0) < 1e-6
+    # unit sphere at the origin, p = (2,0,0): corner distances differ from |p| - 1 by +-T/1 in first
+    # order along x only, so the sum points along +x; the second-order terms are O(T^2 / |p|)
+    lib.orc_kat_normal(e.handle, 0, F3(2.0, 0.0, 0.0), out)
+    assert abs(out[0] - 1.0) < 1e-3 and abs(out[1]) < 2e-3 and abs(out[2]) < 2e-3
     e.close()
 
 
