@@ -335,13 +335,13 @@ struct CellLists {
     int s0, s1, b0, b1;
     float reach;  // every primitive outside the lists is at least this far from p
 };
-RM_DEV CellLists grid_cell(const GridView &gv, V3 p) {
+RM_DEV CellLists grid_cell(const GridView &gv, const GridLevel &lv, V3 p) {
     const float fx = (p.x - gv.ox) * gv.inv_cell, fy = (p.y - gv.oy) * gv.inv_cell, fz = (p.z - gv.oz) * gv.inv_cell;
     const bool inside = fx >= 0.0f && fx < (float)gv.nx && fy >= 0.0f && fy < (float)gv.ny && fz >= 0.0f && fz < (float)gv.nz;
     CellLists c = {0, 0, 0, 0, gv.reach};
     if (inside) {
         const int cell = ((int)fz * gv.ny + (int)fy) * gv.nx + (int)fx;  // non-negative: truncation is floor
-        const Int4 rec = ((ConstInt4s)gv.cell)[cell];  // one 16-byte record: first sphere, first box, counts, reach
+        const Int4 rec = ((ConstInt4s)lv.cell)[cell];  // one 16-byte record: first sphere, first box, counts, reach
         c.s0 = rec.x;
         c.s1 = rec.x + (rec.z & 0xffff);
         c.b0 = rec.y;
@@ -366,10 +366,11 @@ RM_DEV CellLists grid_cell(const GridView &gv, V3 p) {
 //     more than k below the minimum of what was folded, so at that turn the gap is >= k in both
 //     folds, both take exactly s (<= R - 2k), and from there on they agree.  (`slack` keeps the
 //     comparison clear of the rounding of the two sums.)
-template <class SC, class IGN>
+template <int LEVEL, class SC, class IGN>
 RM_DEV bool grid_fold(const SC &sc, V3 p, const IGN &ign, float &r, float k, bool blend) {
     const GridView &gv = sc.grid();
-    const CellLists c = grid_cell(gv, p);
+    const GridLevel &lv = gv.level[LEVEL];
+    const CellLists c = grid_cell(gv, lv, p);
     const float R = c.reach;
     bool certain = r <= R - k;  // blend only
     float floor_before = rs_min(r, R);
@@ -389,8 +390,8 @@ RM_DEV bool grid_fold(const SC &sc, V3 p, const IGN &ign, float &r, float k, boo
     };
     // Entries are fetched four (boxes: two) at a time before any is used, so that a list costs one
     // memory round trip per group instead of one per entry; they are folded one by one, in order.
-    const ConstFloat4s sph_geom = (ConstFloat4s)gv.sph_geom, box_geom = (ConstFloat4s)gv.box_geom;
-    const ConstInts sph_index = constant(gv.sph_index), box_index = constant(gv.box_index);
+    const ConstFloat4s sph_geom = (ConstFloat4s)lv.sph_geom, box_geom = (ConstFloat4s)lv.box_geom;
+    const ConstInts sph_index = constant(lv.sph_index), box_index = constant(lv.box_index);
     for (int e = c.s0; e < c.s1; e += 4) {
         Float4 g[4];
         int oi[4];
@@ -471,11 +472,14 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, bool active, SphereBo
     if constexpr (SC::kGrid) {
         if (sc.grid().cells > 0) {
             if (!active) return d;
+            // the cell's short lists first, its long lists if those leave the value open, and the
+            // full walk below if these do too
             float r = d;
             diag_event(6);
-            if (grid_fold(sc, p, ign, r, k, blend)) return r;
+            if (grid_fold<0>(sc, p, ign, r, k, blend)) return r;
+            r = d;
+            if (grid_fold<1>(sc, p, ign, r, k, blend)) return r;
             diag_event(7);
-            // not certain from the cell's lists alone: the full walk below settles it
         }
     }
     // spheres: the whole group is skipped while the carried bound proves it irrelevant (with a
@@ -530,22 +534,27 @@ RM_DEV int closest_index(const SC &sc, V3 p, float, const IGN &ign) {
     });
     if constexpr (SC::kGrid) {
         if (sc.grid().cells > 0) {
-            // the primitives missing from the cell's lists are at least `reach` away: a best
-            // distance below that cannot be theirs
+            // the primitives missing from a cell's lists are at least its reach away: a best
+            // distance below that cannot be theirs (re-taking a primitive changes nothing)
             const GridView &gv = sc.grid();
-            const CellLists c = grid_cell(gv, p);
-            for (int e = c.s0; e < c.s1; e++) {
-                const float4 g = reinterpret_cast<const float4 *>(gv.sph_geom)[e];
-                const int oi = gv.sph_index[e];
-                if (!ign.skip(oi)) take(oi, sqrt_rn(mag_sqd(p - v3(g.x, g.y, g.z))) - g.w);
-            }
-            for (int e = c.b0; e < c.b1; e++) {
-                const float4 g0 = reinterpret_cast<const float4 *>(gv.box_geom)[2 * e];
-                const float4 g1 = reinterpret_cast<const float4 *>(gv.box_geom)[2 * e + 1];
-                const int oi = gv.box_index[e];
-                if (!ign.skip(oi)) take(oi, box_sdf(v3(g0.x, g0.y, g0.z), v3(g0.w, g1.x, g1.y), p));
-            }
-            if (best < c.reach) return bi;
+            auto take_lists = [&](const GridLevel &lv) {
+                const CellLists c = grid_cell(gv, lv, p);
+                const ConstFloat4s sph_geom = (ConstFloat4s)lv.sph_geom, box_geom = (ConstFloat4s)lv.box_geom;
+                const ConstInts sph_index = constant(lv.sph_index), box_index = constant(lv.box_index);
+                for (int e = c.s0; e < c.s1; e++) {
+                    const Float4 g = sph_geom[e];
+                    const int oi = sph_index[e];
+                    if (!ign.skip(oi)) take(oi, sqrt_rn(mag_sqd(p - v3(g.x, g.y, g.z))) - g.w);
+                }
+                for (int e = c.b0; e < c.b1; e++) {
+                    const Float4 g0 = box_geom[2 * e], g1 = box_geom[2 * e + 1];
+                    const int oi = box_index[e];
+                    if (!ign.skip(oi)) take(oi, box_sdf(v3(g0.x, g0.y, g0.z), v3(g0.w, g1.x, g1.y), p));
+                }
+                return c.reach;
+            };
+            if (best < take_lists(gv.level[0])) return bi;
+            if (best < take_lists(gv.level[1])) return bi;
         }
     }
     sc.spheres([&](int, int oi, float cx, float cy, float cz, float r) {

@@ -470,6 +470,7 @@ constexpr int kGridMinPrimitives = 16;  // fewer bounded primitives than this: n
 constexpr int kGridMaxDim = 48;         // cells per axis at most
 constexpr int kGridMinList = 6;         // a cell lists at least this many primitives (its reach grows to admit them)
 constexpr int kGridMaxList = 48;        // and at most this many (its reach shrinks)
+constexpr int kGridShortList = 4;       // the short lists tried first: this many nearest primitives per cell
 
 struct rm_engine {
     int device = 0;
@@ -783,6 +784,7 @@ static int engine_upload(rm_engine *e) {
                 const double cell_mul = getenv("RM_GRID_CELL") ? atof(getenv("RM_GRID_CELL")) : 0.25;
                 const int min_list = getenv("RM_GRID_MINLIST") ? atoi(getenv("RM_GRID_MINLIST")) : kGridMinList;
                 const int max_list = getenv("RM_GRID_MAXLIST") ? atoi(getenv("RM_GRID_MAXLIST")) : kGridMaxList;
+                const int short_list = getenv("RM_GRID_SHORTLIST") ? atoi(getenv("RM_GRID_SHORTLIST")) : kGridShortList;
                 const float reach = (float)(reach_mul * spacing + 2.0 * s.smooth_k);
                 // the grid spans the primitives and half their extent around them; beyond it every
                 // primitive is at least `apron` away
@@ -802,8 +804,21 @@ static int engine_upload(rm_engine *e) {
                 gv.ny = std::max(1, (int)std::ceil((bhi[1] + apron + margin - gv.oy) / cell));
                 gv.nz = std::max(1, (int)std::ceil((bhi[2] + apron + margin - gv.oz) / cell));
                 gv.cells = gv.nx * gv.ny * gv.nz;
-                std::vector<int> s_start(gv.cells + 1, 0), b_start(gv.cells + 1, 0), s_index, b_index;
-                std::vector<float> s_geom, b_geom, cell_reach(gv.cells, 0.0f);
+                // per level: base reach, fewest and most primitives a cell lists.  Level 0 holds the few
+                // nearest primitives of every cell and nothing else; level 1 everything within `reach`.
+                struct LevelPlan {
+                    float base;
+                    int min_list, max_list;
+                } plans[kGridLevels] = {{0.0f, short_list, short_list}, {reach, min_list, max_list}};
+                struct LevelData {
+                    std::vector<int> s_start, b_start, s_index, b_index;
+                    std::vector<float> s_geom, b_geom, cell_reach;
+                } lv[kGridLevels];
+                for (auto &l : lv) {
+                    l.s_start.assign(gv.cells + 1, 0);
+                    l.b_start.assign(gv.cells + 1, 0);
+                    l.cell_reach.assign(gv.cells, 0.0f);
+                }
                 std::vector<float> lb(n_bounded), sorted(n_bounded);
                 const float origin[3] = {gv.ox, gv.oy, gv.oz};
                 for (int cz = 0; cz < gv.nz; cz++)
@@ -836,50 +851,56 @@ static int engine_upload(rm_engine *e) {
                                     lb[i] = (float)std::sqrt(d2) - margin;
                                 }
                             }
-                            // the cell's reach: every primitive with lb < r is listed, every other is >= r away
                             sorted = lb;
                             std::sort(sorted.begin(), sorted.end());
-                            float r = reach;
-                            const int want = std::min(min_list, n_bounded);
-                            if (want > 0 && !(sorted[want - 1] < r))
-                                r = want < n_bounded ? std::nextafter(sorted[want - 1], INFINITY) : INFINITY;
-                            if (n_bounded > max_list && sorted[max_list] < r) r = sorted[max_list];
-                            cell_reach[c] = r;
-                            for (int i = 0; i < n_bounded; i++) {
-                                if (!(lb[i] < r)) continue;
-                                if (i < (int)gi_sph.size()) {
-                                    s_index.push_back(gi_sph[i]);
-                                    s_geom.insert(s_geom.end(), &g_sph[4 * i], &g_sph[4 * i] + 4);
-                                } else {
-                                    const int b = i - (int)gi_sph.size();
-                                    b_index.push_back(gi_box[b]);
-                                    b_geom.insert(b_geom.end(), &g_box[8 * b], &g_box[8 * b] + 8);
+                            for (int L = 0; L < kGridLevels; L++) {
+                                // the cell's reach: every primitive with lb < r is listed, every other is >= r away
+                                float r = plans[L].base;
+                                const int want = std::min(plans[L].min_list, n_bounded);
+                                if (want > 0 && !(sorted[want - 1] < r))
+                                    r = want < n_bounded ? std::nextafter(sorted[want - 1], INFINITY) : INFINITY;
+                                if (n_bounded > plans[L].max_list && sorted[plans[L].max_list] < r) r = sorted[plans[L].max_list];
+                                lv[L].cell_reach[c] = r;
+                                for (int i = 0; i < n_bounded; i++) {
+                                    if (!(lb[i] < r)) continue;
+                                    if (i < (int)gi_sph.size()) {
+                                        lv[L].s_index.push_back(gi_sph[i]);
+                                        lv[L].s_geom.insert(lv[L].s_geom.end(), &g_sph[4 * i], &g_sph[4 * i] + 4);
+                                    } else {
+                                        const int b = i - (int)gi_sph.size();
+                                        lv[L].b_index.push_back(gi_box[b]);
+                                        lv[L].b_geom.insert(lv[L].b_geom.end(), &g_box[8 * b], &g_box[8 * b] + 8);
+                                    }
                                 }
+                                lv[L].s_start[c + 1] = (int)lv[L].s_index.size();
+                                lv[L].b_start[c + 1] = (int)lv[L].b_index.size();
                             }
-                            s_start[c + 1] = (int)s_index.size();
-                            b_start[c + 1] = (int)b_index.size();
                         }
-                std::vector<int> cell_rec(4 * (size_t)gv.cells);
-                for (int c = 0; c < gv.cells; c++) {
-                    cell_rec[4 * c] = s_start[c];
-                    cell_rec[4 * c + 1] = b_start[c];
-                    cell_rec[4 * c + 2] = (s_start[c + 1] - s_start[c]) | ((b_start[c + 1] - b_start[c]) << 16);
-                    memcpy(&cell_rec[4 * c + 3], &cell_reach[c], sizeof(float));
+                e->grid_entries = 0;
+                for (int L = 0; L < kGridLevels; L++) {
+                    std::vector<int> cell_rec(4 * (size_t)gv.cells);
+                    for (int c = 0; c < gv.cells; c++) {
+                        cell_rec[4 * c] = lv[L].s_start[c];
+                        cell_rec[4 * c + 1] = lv[L].b_start[c];
+                        cell_rec[4 * c + 2] = (lv[L].s_start[c + 1] - lv[L].s_start[c]) | ((lv[L].b_start[c + 1] - lv[L].b_start[c]) << 16);
+                        memcpy(&cell_rec[4 * c + 3], &lv[L].cell_reach[c], sizeof(float));
+                    }
+                    HIP_TRY(up_i(cell_rec, &gv.level[L].cell));
+                    HIP_TRY(up_f(lv[L].s_geom, &gv.level[L].sph_geom));
+                    HIP_TRY(up_i(lv[L].s_index, &gv.level[L].sph_index));
+                    HIP_TRY(up_f(lv[L].b_geom, &gv.level[L].box_geom));
+                    HIP_TRY(up_i(lv[L].b_index, &gv.level[L].box_index));
+                    e->grid_entries += lv[L].s_index.size() + lv[L].b_index.size();
+                    if (getenv("RM_VERBOSE")) {
+                        int longest_list = 0;
+                        for (int c = 0; c < gv.cells; c++)
+                            longest_list = std::max(longest_list, lv[L].s_start[c + 1] - lv[L].s_start[c] + lv[L].b_start[c + 1] - lv[L].b_start[c]);
+                        const size_t entries = lv[L].s_index.size() + lv[L].b_index.size();
+                        fprintf(stderr, "rm: spatial index level %d: %d x %d x %d cells of %.3f, base reach %.3f, apron %.3f, %zu entries (%.1f per cell, longest list %d) for %d primitives\n",
+                                L, gv.nx, gv.ny, gv.nz, cell, plans[L].base, apron, entries, (double)entries / gv.cells, longest_list, n_bounded);
+                    }
                 }
-                HIP_TRY(up_i(cell_rec, &gv.cell));
-                HIP_TRY(up_f(s_geom, &gv.sph_geom));
-                HIP_TRY(up_i(s_index, &gv.sph_index));
-                HIP_TRY(up_f(b_geom, &gv.box_geom));
-                HIP_TRY(up_i(b_index, &gv.box_index));
                 gl.grid = gv;
-                e->grid_entries = s_index.size() + b_index.size();
-                if (getenv("RM_VERBOSE")) {
-                    int longest_list = 0;
-                    for (int c = 0; c < gv.cells; c++)
-                        longest_list = std::max(longest_list, s_start[c + 1] - s_start[c] + b_start[c + 1] - b_start[c]);
-                    fprintf(stderr, "rm: spatial index %d x %d x %d cells of %.3f, base reach %.3f, apron %.3f, %zu entries (%.1f per cell, longest list %d) for %d primitives\n",
-                            gv.nx, gv.ny, gv.nz, cell, reach, apron, e->grid_entries, (double)e->grid_entries / gv.cells, longest_list, n_bounded);
-                }
             }
         }
     }

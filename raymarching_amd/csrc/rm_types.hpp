@@ -74,21 +74,26 @@ typedef GroupedSmall<2, 2, 0> GroupedTierA;
 typedef GroupedSmall<4, 4, 2> GroupedTierB;
 
 // Spatial index over the bounded primitives (spheres, boxes) of a large scene.  Every cell of a
-// uniform grid lists the primitives that come within `reach` of any point of the cell, spheres
-// and boxes separately, each list in ascending object index with the geometry stored in place.
-// A primitive missing from a cell's lists is at least that cell's reach away from every point of
-// the cell; a point outside the grid is at least `reach` away from every primitive.  cells == 0: no
-// index.
-struct GridView {
-    int nx, ny, nz, cells;
-    float ox, oy, oz;   // lower corner
-    float inv_cell;     // 1 / edge length
-    float reach;            // outside the grid
+// uniform grid lists the primitives that come within the cell's reach of any point of the cell,
+// spheres and boxes separately, each list in ascending object index with the geometry stored in
+// place.  A primitive missing from a cell's lists is at least that cell's reach away from every
+// point of the cell; a point outside the grid is at least `reach` away from every primitive.
+// There are two sets of lists over the same cells: a short one (the few nearest primitives of the
+// cell), tried first, and a long one (everything within a wider reach).  cells == 0: no index.
+constexpr int kGridLevels = 2;
+struct GridLevel {
     const int *cell;        // [cells][4]: first sphere entry, first box entry, sphere count | box count << 16, reach (float bits)
     const float *sph_geom;  // [entries][4]: cx, cy, cz, r
     const int *sph_index;   // [entries]: object index
     const float *box_geom;  // [entries][8]: cx, cy, cz, hx, hy, hz, -, -
     const int *box_index;
+};
+struct GridView {
+    int nx, ny, nz, cells;
+    float ox, oy, oz;   // lower corner
+    float inv_cell;     // 1 / edge length
+    float reach;        // outside the grid
+    GridLevel level[kGridLevels];
 };
 
 struct GroupedLarge {
