@@ -507,12 +507,13 @@ struct rm_engine {
     unsigned char *d_frame = nullptr;  // W*H*4, for rm_engine_render
     unsigned char *h_stage = nullptr;  // pinned W*H*4 staging for callers that pass pageable memory
 
-    // frames in flight for rm_engine_render_async: render on `stream`, copy out on `copy_stream`
+    // frames in flight for rm_engine_render_async: each slot renders and copies out on a stream of its
+    // own, so that consecutive frames overlap (the long-running tiles of one beside the bulk of the next)
     unsigned char *d_async[RM_FRAMES_IN_FLIGHT] = {};
-    hipEvent_t ev_rendered[RM_FRAMES_IN_FLIGHT] = {};
+    hipStream_t slot_stream[RM_FRAMES_IN_FLIGHT] = {};
+    hipEvent_t ev_main = nullptr;  // orders a slot after what the engine's own stream was given before
     hipEvent_t ev_copied[RM_FRAMES_IN_FLIGHT] = {};
     bool async_pending[RM_FRAMES_IN_FLIGHT] = {};
-    hipStream_t copy_stream = nullptr;
     int async_head = 0;  // slot the next frame goes to
     int async_tail = 0;  // oldest pending slot
 
@@ -953,10 +954,10 @@ static void engine_free(rm_engine *e) {
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (int i = 0; i < RM_FRAMES_IN_FLIGHT; i++) {
         (void)hipFree(e->d_async[i]);
-        if (e->ev_rendered[i]) (void)hipEventDestroy(e->ev_rendered[i]);
         if (e->ev_copied[i]) (void)hipEventDestroy(e->ev_copied[i]);
+        if (e->slot_stream[i]) (void)hipStreamDestroy(e->slot_stream[i]);
     }
-    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    if (e->ev_main) (void)hipEventDestroy(e->ev_main);
     (void)hipFree(e->d_patch_obj);
     (void)hipFree(e->d_pos);
     (void)hipFree(e->d_col);
@@ -1297,22 +1298,26 @@ int rm_engine_render_async(rm_engine *e, uint8_t *bgra, size_t pitch_bytes, int3
         int rc = rm_engine_render_wait(e);
         if (rc) return rc;
     }
-    if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    if (!e->ev_main) HIP_TRY(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
     if (!e->d_async[slot]) {
         HIP_TRY(dev_alloc(&e->d_async[slot], (size_t)e->W * e->H * 4));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_rendered[slot], hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[slot], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_copied[slot], hipEventDisableTiming));
     }
     int rc = rm_engine_input(e, mouse_x, mouse_y, rel_move, scroll);
     if (rc) return rc;
+    // whatever the engine's stream holds so far (lightmaps, an earlier synchronous frame) comes first
+    HIP_TRY(hipEventRecord(e->ev_main, e->stream));
+    HIP_TRY(hipStreamWaitEvent(e->slot_stream[slot], e->ev_main, 0));
     // the previous copy out of this slot has finished (its frame was waited for), so it can be overwritten
+    hipStream_t own = e->stream;
+    e->stream = e->slot_stream[slot];
     rc = rm_engine_render_rows_device(e, e->d_async[slot], (size_t)e->W * 4, 0, e->H);
+    e->stream = own;
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(e->ev_rendered[slot], e->stream));
-    HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_rendered[slot], 0));
     HIP_TRY(hipMemcpy2DAsync(bgra, pitch_bytes, e->d_async[slot], (size_t)e->W * 4, (size_t)e->W * 4, e->H,
-                             hipMemcpyDeviceToHost, e->copy_stream));
-    HIP_TRY(hipEventRecord(e->ev_copied[slot], e->copy_stream));
+                             hipMemcpyDeviceToHost, e->slot_stream[slot]));
+    HIP_TRY(hipEventRecord(e->ev_copied[slot], e->slot_stream[slot]));
     e->async_pending[slot] = true;
     e->async_head = (slot + 1) % RM_FRAMES_IN_FLIGHT;
     return RM_OK;
@@ -1558,8 +1563,7 @@ extern "C" int rm_diag_read(rm_engine *e, uint64_t out[kStatSlots]) {
 int rm_engine_get_stats(rm_engine *e, uint64_t stats[RM_STAT_COUNT]) {
     if (!e || !stats) return fail(RM_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(e->device));
-    if (int rc_ = sync_view(e)) return rc_;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (int rc_ = rm_engine_synchronize(e)) return rc_;  // frames in flight count too
     HIP_TRY(hipMemcpy(stats, e->d_stats, sizeof(uint64_t) * RM_STAT_COUNT, hipMemcpyDeviceToHost));
     return RM_OK;
 }
@@ -1576,6 +1580,8 @@ int rm_engine_synchronize(rm_engine *e) {
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_ = sync_view(e)) return rc_;
     HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < RM_FRAMES_IN_FLIGHT; i++)
+        if (e->slot_stream[i]) HIP_TRY(hipStreamSynchronize(e->slot_stream[i]));
     return RM_OK;
 }
 

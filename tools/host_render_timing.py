@@ -8,7 +8,7 @@ import numpy as np
 
 from raymarching_amd import Engine, default_scene
 
-W, H = 3840, 2160
+W, H = int(os.environ.get("RM_W", 3840)), int(os.environ.get("RM_H", 2160))
 eng = Engine(default_scene(), W, H)
 eng.compute_lightmaps(4)
 buf = np.empty((H, W, 4), dtype=np.uint8)
@@ -21,7 +21,7 @@ for _ in range(30):
     t.append(time.perf_counter() - t0)
 t.sort()
 med = t[len(t) // 2]
-print(f"rm_engine_render 4K into pageable host memory: median {med*1e3:.3f} ms -> {W*H/med/1e6:.0f} Mrays/s")
+print(f"rm_engine_render {W}x{H} into pageable host memory: median {med*1e3:.3f} ms -> {W*H/med/1e6:.0f} Mrays/s")
 
 import ctypes
 
@@ -39,7 +39,7 @@ for _ in range(30):
     t.append(time.perf_counter() - t0)
 t.sort()
 med = t[len(t) // 2]
-print(f"rm_engine_render 4K into rm_host_alloc memory: median {med*1e3:.3f} ms -> {W*H/med/1e6:.0f} Mrays/s")
+print(f"rm_engine_render {W}x{H} into rm_host_alloc memory: median {med*1e3:.3f} ms -> {W*H/med/1e6:.0f} Mrays/s")
 assert np.array_equal(pinned, buf)
 
 # pipelined: the copy of frame f overlaps the render of frame f+1
@@ -56,6 +56,6 @@ for f in range(N):
 eng.render_wait()
 eng.render_wait()
 dt = (time.perf_counter() - t0) / N
-print(f"rm_engine_render_async 4K, two frames in flight: {dt*1e3:.3f} ms per frame -> {W*H/dt/1e6:.0f} Mrays/s")
+print(f"rm_engine_render_async {W}x{H}, two frames in flight: {dt*1e3:.3f} ms per frame -> {W*H/dt/1e6:.0f} Mrays/s")
 lib.rm_host_free(ptr)
 lib.rm_host_free(ptr2)
