@@ -306,12 +306,16 @@ struct SphereBound {
     float dn;   // per ray
     float M;
     float eps;  // 2e-6 (P + C): more than any sphere distance differs from its one-ulp estimate
+    // The lane's last evaluation left the spheres out: each is then strictly farther than the value
+    // found (M exceeds the rounding it covers), so none of them can be the closest object either.
+    bool spheres_out;
 };
 
 template <class SC>
 RM_DEV SphereBound make_bound(const SC &sc, V3 o, V3 dir, float tmax) {
     SphereBound b;
     b.T = -__builtin_inff();
+    b.spheres_out = false;
     const float amax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
     const float dmax = fmaxf(fmaxf(fabsf(dir.x), fabsf(dir.y)), fabsf(dir.z));
     const float P = (amax + tmax * dmax) * 1.001f + 1.0f;
@@ -485,6 +489,7 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, bool active, SphereBo
     // spheres: the whole group is skipped while the carried bound proves it irrelevant (with a
     // smooth union a sphere matters only within k of the running value)
     const float reach = __builtin_fmaf(travelled, sb.dn, blend ? d + k : d);
+    if (active) sb.spheres_out = reach <= sb.T;
     if (active && !(reach <= sb.T)) {
         diag_event(3);
         // The bound only needs each distance to within a few ulp: the hardware square root (one
@@ -510,7 +515,7 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, bool active, SphereBo
 // The hit object: smallest own distance, lowest index on ties (the strict `<` of ray.rs:29);
 // every object is evaluated exactly here.
 template <class SC, class IGN>
-RM_DEV int closest_index(const SC &sc, V3 p, float, const IGN &ign) {
+RM_DEV int closest_index(const SC &sc, V3 p, float, const IGN &ign, bool spheres_out = false) {
     float best = __builtin_inff();
     int bi = 0x7fffffff;
     auto take = [&](int oi, float s0) {
@@ -557,9 +562,10 @@ RM_DEV int closest_index(const SC &sc, V3 p, float, const IGN &ign) {
             if (best < take_lists(gv.level[1])) return bi;
         }
     }
-    sc.spheres([&](int, int oi, float cx, float cy, float cz, float r) {
-        if (!ign.skip(oi)) take(oi, sqrt_rn(mag_sqd(p - v3(cx, cy, cz))) - r);
-    });
+    if (!(spheres_out && !SC::kGrid))  // (with a spatial index the bound is not kept up on every step)
+        sc.spheres([&](int, int oi, float cx, float cy, float cz, float r) {
+            if (!ign.skip(oi)) take(oi, sqrt_rn(mag_sqd(p - v3(cx, cy, cz))) - r);
+        });
     sc.boxes([&](int oi, V3 c, V3 h) {
         if (!ign.skip(oi)) take(oi, box_sdf(c, h, p));
     });
@@ -590,7 +596,7 @@ RM_DEV int march_capped(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, 
         travelled += d;
         pos = pos + dir * d;
     }
-    return hit ? closest_index(sc, pos, d, ign) : -1;
+    return hit ? closest_index(sc, pos, d, ign, sb.spheres_out) : -1;
 }
 
 // The same loop for the usual case of no iteration cap, written so that the wave
@@ -624,7 +630,7 @@ RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, in
         active = go && (t2 < MAX_MARCH_DISTANCE);
     } while (wave_any(active));
     diag_lap(DG_MARCH_LOOP);
-    const int idx = hit ? closest_index(sc, pos, d_hit, ign) : -1;
+    const int idx = hit ? closest_index(sc, pos, d_hit, ign, sb.spheres_out) : -1;
     diag_lap(DG_CLOSEST);
     return idx;
 }
