@@ -75,6 +75,15 @@ RM_DEV void diag_lap(int) {}
 RM_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 RM_DEV bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0; }
 
+// The set of lanes a loop still works for, held as a 64-bit mask in scalar registers: comparisons
+// deliver such masks directly, the scalar unit combines them, and the loop's exit test is a scalar
+// compare with zero.  lanes_in() turns a mask back into a per-lane predicate for selects.
+typedef unsigned long long LaneMask;
+RM_DEV LaneMask lanes_here() { return __builtin_amdgcn_ballot_w64(true); }
+RM_DEV bool lanes_in(LaneMask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+RM_DEV LaneMask lanes_lt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 4); }  // ordered a < b
+RM_DEV LaneMask lanes_gt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 2); }  // ordered a > b
+
 struct V3 {
     float x, y, z;
 };
@@ -308,14 +317,14 @@ struct SphereBound {
     float eps;  // 2e-6 (P + C): more than any sphere distance differs from its one-ulp estimate
     // The lane's last evaluation left the spheres out: each is then strictly farther than the value
     // found (M exceeds the rounding it covers), so none of them can be the closest object either.
-    bool spheres_out;
+    LaneMask spheres_out;
 };
 
 template <class SC>
 RM_DEV SphereBound make_bound(const SC &sc, V3 o, V3 dir, float tmax) {
     SphereBound b;
     b.T = -__builtin_inff();
-    b.spheres_out = false;
+    b.spheres_out = 0;
     const float amax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
     const float dmax = fmaxf(fmaxf(fabsf(dir.x), fabsf(dir.y)), fabsf(dir.z));
     const float P = (amax + tmax * dmax) * 1.001f + 1.0f;
@@ -441,7 +450,8 @@ RM_DEV bool grid_fold(const SC &sc, V3 p, const IGN &ign, float &r, float k, boo
 // `active` marks the lanes whose result is used: a finished lane must not pull the rest of its
 // wave into the sphere evaluation.
 template <class SC, class IGN>
-RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, bool active, SphereBound &sb, float travelled) {
+RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, LaneMask act, SphereBound &sb, float travelled) {
+    const bool active = lanes_in(act);
     const float k = sc.smooth_k();
     const bool blend = SC::kSmooth && k > 0.0f;  // wave-uniform
     float d = __builtin_inff();
@@ -489,7 +499,7 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, bool active, SphereBo
     // spheres: the whole group is skipped while the carried bound proves it irrelevant (with a
     // smooth union a sphere matters only within k of the running value)
     const float reach = __builtin_fmaf(travelled, sb.dn, blend ? d + k : d);
-    if (active) sb.spheres_out = reach <= sb.T;
+    sb.spheres_out = (sb.spheres_out & ~act) | (act & __builtin_amdgcn_fcmpf(reach, sb.T, 5));  // ordered <=
     if (active && !(reach <= sb.T)) {
         diag_event(3);
         // The bound only needs each distance to within a few ulp: the hardware square root (one
@@ -588,7 +598,7 @@ RM_DEV int march_capped(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, 
             return -1;
         }
         steps++;
-        d = scene_min(sc, pos, ign, true, sb, travelled);
+        d = scene_min(sc, pos, ign, lanes_here(), sb, travelled);
         if (d < SMALL_DISTANCE) {
             hit = true;
             break;
@@ -596,7 +606,7 @@ RM_DEV int march_capped(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, 
         travelled += d;
         pos = pos + dir * d;
     }
-    return hit ? closest_index(sc, pos, d, ign, sb.spheres_out) : -1;
+    return hit ? closest_index(sc, pos, d, ign, lanes_in(sb.spheres_out)) : -1;
 }
 
 // The same loop for the usual case of no iteration cap, written so that the wave
@@ -608,18 +618,17 @@ RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, in
     capped = false;
     steps = 0;
     float travelled = 0.0f;
-    float d_hit = 0.0f;
-    bool hit = false;
-    bool active = true;  // travelled = 0 < MAX_MARCH_DISTANCE
+    LaneMask act = lanes_here();  // travelled = 0 < MAX_MARCH_DISTANCE
+    LaneMask hit_lanes = 0;
     SphereBound sb = make_bound(sc, pos, dir, MAX_MARCH_DISTANCE);
     do {
+        const bool active = lanes_in(act);
         diag_iter(active, 1);
-        const float d = scene_min(sc, pos, ign, active, sb, travelled);
-        const bool near = d < SMALL_DISTANCE;
-        const bool hit_now = active && near;
-        const bool go = active && !near;
-        hit = hit || hit_now;
-        d_hit = hit_now ? d : d_hit;
+        const float d = scene_min(sc, pos, ign, act, sb, travelled);
+        const LaneMask near = lanes_lt(d, SMALL_DISTANCE);
+        hit_lanes |= act & near;
+        const LaneMask go_lanes = act & ~near;
+        const bool go = lanes_in(go_lanes);
         steps += active ? 1 : 0;
         const float t2 = travelled + d;
         const V3 p2 = pos + dir * d;
@@ -627,10 +636,12 @@ RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, in
         pos.x = go ? p2.x : pos.x;
         pos.y = go ? p2.y : pos.y;
         pos.z = go ? p2.z : pos.z;
-        active = go && (t2 < MAX_MARCH_DISTANCE);
-    } while (wave_any(active));
+        act = go_lanes & lanes_lt(t2, MAX_MARCH_DISTANCE);
+    } while (act != 0);
+    const bool hit = lanes_in(hit_lanes);
+    const float d_hit = 0.0f;
     diag_lap(DG_MARCH_LOOP);
-    const int idx = hit ? closest_index(sc, pos, d_hit, ign, sb.spheres_out) : -1;
+    const int idx = hit ? closest_index(sc, pos, d_hit, ign, lanes_in(sb.spheres_out)) : -1;
     diag_lap(DG_CLOSEST);
     return idx;
 }
@@ -653,11 +664,12 @@ template <class SC, class IGN>
 RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float light_dist, float k) {
     float travelled = 0.0f;
     float shade = 1.0f;
-    bool active = true;
+    LaneMask act = lanes_here();
     SphereBound sb = make_bound(sc, pos, dir, light_dist);
     for (int it = 0; it < MAX_SHAD_IT; it++) {
+        const bool active = lanes_in(act);
         diag_iter(active, 2);
-        const float d = scene_min(sc, pos, ign, active, sb, travelled);
+        const float d = scene_min(sc, pos, ign, act, sb, travelled);
         // shade = min(shade, smoothstep(clamp(k*d / travelled, 0, 1))).  With a = k*d >= travelled
         // >= 0 the correctly rounded quotient is >= 1 (or +inf, or NaN for 0/0): the clamp gives 1
         // (or keeps the NaN), smoothstep(1) = 1, and min(shade, 1 or NaN) leaves shade (<= 1) as it
@@ -677,8 +689,8 @@ RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float lig
         pos.x = active ? p2.x : pos.x;
         pos.y = active ? p2.y : pos.y;
         pos.z = active ? p2.z : pos.z;
-        active = active && !(d < SMALL_DISTANCE || t2 > light_dist);
-        if (!wave_any(active)) break;
+        act &= ~(lanes_lt(d, SMALL_DISTANCE) | lanes_gt(t2, light_dist));
+        if (act == 0) break;
     }
     return rs_clamp(shade, 0.0f, 1.0f);
 }
