@@ -499,8 +499,9 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, LaneMask act, SphereB
     // spheres: the whole group is skipped while the carried bound proves it irrelevant (with a
     // smooth union a sphere matters only within k of the running value)
     const float reach = __builtin_fmaf(travelled, sb.dn, blend ? d + k : d);
-    sb.spheres_out = (sb.spheres_out & ~act) | (act & __builtin_amdgcn_fcmpf(reach, sb.T, 5));  // ordered <=
-    if (active && !(reach <= sb.T)) {
+    const LaneMask within = __builtin_amdgcn_fcmpf(reach, sb.T, 5);  // ordered reach <= T: the spheres stay out
+    sb.spheres_out = (sb.spheres_out & ~act) | (act & within);
+    if (lanes_in(act & ~within)) {
         diag_event(3);
         // The bound only needs each distance to within a few ulp: the hardware square root (one
         // ulp) serves.  The correctly rounded value is computed only for a sphere that comes
@@ -632,7 +633,7 @@ RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, in
         steps += active ? 1 : 0;
         const float t2 = travelled + d;
         const V3 p2 = pos + dir * d;
-        travelled = go ? t2 : travelled;
+        travelled = t2;  // (read by running lanes only)
         pos.x = go ? p2.x : pos.x;
         pos.y = go ? p2.y : pos.y;
         pos.z = go ? p2.z : pos.z;
@@ -682,14 +683,11 @@ RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float lig
             const float ss = 3.0f * (x * x) - 2.0f * (x * (x * x));
             sh2 = rs_min(shade, ss);
         }
-        const float t2 = travelled + d;
-        const V3 p2 = pos + dir * d;
-        shade = active ? sh2 : shade;
-        travelled = active ? t2 : travelled;
-        pos.x = active ? p2.x : pos.x;
-        pos.y = active ? p2.y : pos.y;
-        pos.z = active ? p2.z : pos.z;
-        act &= ~(lanes_lt(d, SMALL_DISTANCE) | lanes_gt(t2, light_dist));
+        shade = sh2;
+        // a lane that has finished keeps stepping with values nobody reads: only `shade` leaves the loop
+        travelled += d;
+        pos = pos + dir * d;
+        act &= ~(lanes_lt(d, SMALL_DISTANCE) | lanes_gt(travelled, light_dist));
         if (act == 0) break;
     }
     return rs_clamp(shade, 0.0f, 1.0f);
