@@ -466,6 +466,8 @@ struct rm_scene {
 };
 
 constexpr int kStatSlots = 32;
+constexpr int kBands = 8;  // row bands of a frame on its way to the host, at most
+constexpr size_t kBandedFramePixels = 4u << 20;  // smaller frames leave in one piece: their bands would each wait for a slow tile
 constexpr int kGridMinPrimitives = 16;  // fewer bounded primitives than this: no spatial index
 constexpr int kGridMaxDim = 48;         // cells per axis at most
 constexpr int kGridMinList = 6;         // a cell lists at least this many primitives (its reach grows to admit them)
@@ -514,6 +516,10 @@ struct rm_engine {
     hipEvent_t ev_main = nullptr;  // orders a slot after what the engine's own stream was given before
     hipEvent_t ev_copied[RM_FRAMES_IN_FLIGHT] = {};
     bool async_pending[RM_FRAMES_IN_FLIGHT] = {};
+    // rm_engine_render: the frame leaves in row bands, copied out on `xfer_stream` while later bands render
+    hipStream_t xfer_stream = nullptr;
+    hipEvent_t ev_band_rendered[kBands] = {};
+    hipEvent_t ev_band_copied[kBands] = {};
     int async_head = 0;  // slot the next frame goes to
     int async_tail = 0;  // oldest pending slot
 
@@ -958,6 +964,11 @@ static void engine_free(rm_engine *e) {
         if (e->slot_stream[i]) (void)hipStreamDestroy(e->slot_stream[i]);
     }
     if (e->ev_main) (void)hipEventDestroy(e->ev_main);
+    for (int b = 0; b < kBands; b++) {
+        if (e->ev_band_rendered[b]) (void)hipEventDestroy(e->ev_band_rendered[b]);
+        if (e->ev_band_copied[b]) (void)hipEventDestroy(e->ev_band_copied[b]);
+    }
+    if (e->xfer_stream) (void)hipStreamDestroy(e->xfer_stream);
     (void)hipFree(e->d_patch_obj);
     (void)hipFree(e->d_pos);
     (void)hipFree(e->d_col);
@@ -1249,26 +1260,65 @@ int rm_engine_render(rm_engine *e, uint8_t *bgra, size_t pitch_bytes, int32_t mo
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_ = sync_view(e)) return rc_;
     if (!e->d_frame) HIP_TRY(dev_alloc(&e->d_frame, (size_t)e->W * e->H * 4));
-    rc = rm_engine_render_rows_device(e, e->d_frame, (size_t)e->W * 4, 0, e->H);
-    if (rc) return rc;
-    // Pinned destinations (rm_host_alloc) take the copy directly at PCIe rate;
-    // pageable ones go through a pinned staging frame and one host memcpy per row.
+    // Pinned destinations (rm_host_alloc) take the copy directly at PCIe rate; pageable ones go
+    // through a pinned staging frame and a host memcpy.  Either way the frame leaves in kBands row
+    // bands, bottom band first (the expensive one in scenes with a floor): a band is copied out while
+    // the next ones still render, and with a pageable destination the host copies band b out of the
+    // staging frame while band b+1 crosses the bus.
     hipPointerAttribute_t attr;
-    bool pinned = hipPointerGetAttributes(&attr, bgra) == hipSuccess && attr.type == hipMemoryTypeHost;
+    const bool pinned = hipPointerGetAttributes(&attr, bgra) == hipSuccess && attr.type == hipMemoryTypeHost;
     (void)hipGetLastError();  // an unregistered pointer reports an error: not a failure here
+    if (!pinned && !e->h_stage)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_stage), (size_t)e->W * e->H * 4, hipHostMallocDefault));
+    if (!e->xfer_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->xfer_stream, hipStreamNonBlocking));
+        for (int b = 0; b < kBands; b++) {
+            HIP_TRY(hipEventCreateWithFlags(&e->ev_band_rendered[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&e->ev_band_copied[b], hipEventDisableTiming));
+        }
+    }
+    const size_t row_bytes = (size_t)e->W * 4;
+    const int strips = (e->H + RM_STRIP_ROWS - 1) / RM_STRIP_ROWS;
+    int r0s[kBands], r1s[kBands], n_bands = 0;
+    int want = (size_t)e->W * e->H >= kBandedFramePixels ? kBands : 1;
+    if (const char *v = getenv("RM_BANDS")) want = std::max(1, std::min(kBands, atoi(v)));  // tuning aid
+    for (int b = want - 1; b >= 0; b--) {  // bottom band first
+        const int r0 = (int)((long long)strips * b / want) * RM_STRIP_ROWS;
+        const int r1 = std::min(e->H, (int)((long long)strips * (b + 1) / want) * RM_STRIP_ROWS);
+        if (r1 <= r0) continue;
+        r0s[n_bands] = r0;
+        r1s[n_bands] = r1;
+        n_bands++;
+    }
+    for (int b = 0; b < n_bands; b++) {
+        const int r0 = r0s[b], r1 = r1s[b];
+        rc = rm_engine_render_rows_device(e, e->d_frame + (size_t)r0 * row_bytes, row_bytes, r0, r1);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(e->ev_band_rendered[b], e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->xfer_stream, e->ev_band_rendered[b], 0));
+        if (pinned && pitch_bytes == row_bytes)
+            HIP_TRY(hipMemcpyAsync(bgra + (size_t)r0 * row_bytes, e->d_frame + (size_t)r0 * row_bytes, (size_t)(r1 - r0) * row_bytes,
+                                   hipMemcpyDeviceToHost, e->xfer_stream));
+        else if (pinned)
+            HIP_TRY(hipMemcpy2DAsync(bgra + (size_t)r0 * pitch_bytes, pitch_bytes, e->d_frame + (size_t)r0 * row_bytes, row_bytes,
+                                     row_bytes, r1 - r0, hipMemcpyDeviceToHost, e->xfer_stream));
+        else
+            HIP_TRY(hipMemcpyAsync(e->h_stage + (size_t)r0 * row_bytes, e->d_frame + (size_t)r0 * row_bytes,
+                                   (size_t)(r1 - r0) * row_bytes, hipMemcpyDeviceToHost, e->xfer_stream));
+        HIP_TRY(hipEventRecord(e->ev_band_copied[b], e->xfer_stream));
+    }
     if (pinned) {
-        HIP_TRY(hipMemcpy2DAsync(bgra, pitch_bytes, e->d_frame, (size_t)e->W * 4, (size_t)e->W * 4, e->H,
-                                 hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipStreamSynchronize(e->xfer_stream));
         return RM_OK;
     }
-    if (!e->h_stage) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_stage), (size_t)e->W * e->H * 4, hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(e->h_stage, e->d_frame, (size_t)e->W * e->H * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    if (pitch_bytes == (size_t)e->W * 4) {
-        memcpy(bgra, e->h_stage, (size_t)e->W * e->H * 4);
-    } else {
-        for (int y = 0; y < e->H; y++) memcpy(bgra + (size_t)y * pitch_bytes, e->h_stage + (size_t)y * e->W * 4, (size_t)e->W * 4);
+    for (int b = 0; b < n_bands; b++) {
+        HIP_TRY(hipEventSynchronize(e->ev_band_copied[b]));
+        const int r0 = r0s[b], r1 = r1s[b];
+        if (pitch_bytes == row_bytes) {
+            memcpy(bgra + (size_t)r0 * row_bytes, e->h_stage + (size_t)r0 * row_bytes, (size_t)(r1 - r0) * row_bytes);
+        } else {
+            for (int y = r0; y < r1; y++) memcpy(bgra + (size_t)y * pitch_bytes, e->h_stage + (size_t)y * row_bytes, row_bytes);
+        }
     }
     return RM_OK;
 }
@@ -1582,6 +1632,7 @@ int rm_engine_synchronize(rm_engine *e) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     for (int i = 0; i < RM_FRAMES_IN_FLIGHT; i++)
         if (e->slot_stream[i]) HIP_TRY(hipStreamSynchronize(e->slot_stream[i]));
+    if (e->xfer_stream) HIP_TRY(hipStreamSynchronize(e->xfer_stream));
     return RM_OK;
 }
 

@@ -109,3 +109,42 @@ def test_camera_that_is_not_a_number(cam, oracle_lightmaps):
     mx, exact = assert_frames_match(got, ref, f"camera {cam}")
     print(f"camera {cam}: max|d|={mx} exact={exact:.4%} caps={eng.stats()}")
     eng.close()
+
+
+def test_large_frame_leaves_in_bands(oracle_lightmaps):
+    """Frames of 4 Mpixel and more are copied to the host in row bands while later bands render:
+    into pageable memory, into page-locked memory, and with a padded pitch the bytes equal the frame
+    left on the device (1032 rows: the bands do not divide evenly)."""
+    import ctypes
+
+    import torch
+
+    from raymarching_amd import Engine, _lib
+
+    scene = default_scene()
+    lm, _ = oracle_lightmaps
+    w, h = 4104, 1032
+    eng = Engine(scene, w, h)
+    for i in range(eng.n_objects):
+        eng.set_lightmap(i, lm[-1][i])
+    eng.input(-60, 25, (0.1, 0.0, 0.2), 0)  # move once; the renders below keep the pose (zero movement)
+    pageable = eng.render(None, -60, 25, (0.0, 0.0, 0.0), 0)
+    dev = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    eng.render_rows_device(dev.data_ptr(), 0, h)
+    eng.synchronize()
+    ref = dev.cpu().numpy()
+    assert np.array_equal(pageable, ref)
+    lib = _lib.load()
+    pitch = w * 4 + 256
+    for p, what in ((w * 4, "page-locked"), (pitch, "page-locked, padded pitch")):
+        ptr = lib.rm_host_alloc(p * h)
+        view = np.ctypeslib.as_array((ctypes.c_uint8 * (p * h)).from_address(ptr)).reshape(h, p)
+        view[:] = 0xAB
+        _lib.check(lib.rm_engine_render(eng.handle, ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), p, -60, 25, _lib.f3((0.0, 0.0, 0.0)), 0), what)
+        assert np.array_equal(view[:, : w * 4].reshape(h, w, 4), ref), what
+        assert (view[:, w * 4:] == 0xAB).all(), what
+        lib.rm_host_free(ptr)
+    padded = np.full((h, pitch), 0xCD, dtype=np.uint8)  # pageable with a pitch
+    _lib.check(lib.rm_engine_render(eng.handle, padded.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), pitch, -60, 25, _lib.f3((0.0, 0.0, 0.0)), 0), "pageable, padded pitch")
+    assert np.array_equal(padded[:, : w * 4].reshape(h, w, 4), ref) and (padded[:, w * 4:] == 0xCD).all()
+    eng.close()
