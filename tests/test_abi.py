@@ -63,3 +63,20 @@ def test_engine_creation_fails_loudly_without_gpu(scene):
 
     with pytest.raises(_lib.RMError, match="HIP device|hip"):
         Engine(scene, 64, 64)
+
+
+def test_rust_binding_matches_the_header():
+    """bindings/rust/rm-sys/src/lib.rs is generated from include/rm.h (tools/gen_rm_sys.py): the
+    committed file is current, and it declares exactly the functions the ctypes table binds."""
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rm_sys.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = open(os.path.join(root, "bindings", "rust", "rm-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"pub fn (rm_\w+)\(", text))
+    from raymarching_amd import _lib
+
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
