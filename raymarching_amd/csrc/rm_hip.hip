@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rm.h"
@@ -826,63 +827,80 @@ static int engine_upload(rm_engine *e) {
                     l.b_start.assign(gv.cells + 1, 0);
                     l.cell_reach.assign(gv.cells, 0.0f);
                 }
-                std::vector<float> lb(n_bounded), sorted(n_bounded);
                 const float origin[3] = {gv.ox, gv.oy, gv.oz};
-                for (int cz = 0; cz < gv.nz; cz++)
-                    for (int cy = 0; cy < gv.ny; cy++)
-                        for (int cx = 0; cx < gv.nx; cx++) {
-                            const int c = (cz * gv.ny + cy) * gv.nx + cx;
-                            const int ci[3] = {cx, cy, cz};
-                            float clo[3], chi[3];
-                            for (int a = 0; a < 3; a++) {
-                                // the device computes the cell as floor((p - origin) * inv_cell): widen by the margin
-                                clo[a] = origin[a] + (float)ci[a] * cell - margin;
-                                chi[a] = origin[a] + (float)(ci[a] + 1) * cell + margin;
-                            }
-                            // lower bound of every primitive's distance over the cell
-                            for (int i = 0; i < n_bounded; i++) {
-                                const bool is_sphere = i < (int)gi_sph.size();
-                                double d2 = 0.0;
-                                if (is_sphere) {
-                                    const float *g = &g_sph[4 * i];
-                                    for (int a = 0; a < 3; a++) {
-                                        const double t = std::max(0.0, std::max((double)clo[a] - g[a], (double)g[a] - chi[a]));
-                                        d2 += t * t;
-                                    }
-                                    lb[i] = (float)(std::sqrt(d2) - fabs((double)g[3])) - margin;
-                                } else {
-                                    for (int a = 0; a < 3; a++) {
-                                        const double t = std::max(0.0, std::max((double)clo[a] - hi[3 * i + a], (double)lo[3 * i + a] - chi[a]));
-                                        d2 += t * t;
-                                    }
-                                    lb[i] = (float)std::sqrt(d2) - margin;
+                // phase 1, host threads over slabs of cells: every cell's reach and member list per level
+                std::vector<std::vector<uint16_t>> members[kGridLevels];
+                for (auto &m : members) m.resize(gv.cells);
+                auto slab = [&](int z0, int z1) {
+                    std::vector<float> lb(n_bounded), sorted(n_bounded);
+                    for (int cz = z0; cz < z1; cz++)
+                        for (int cy = 0; cy < gv.ny; cy++)
+                            for (int cx = 0; cx < gv.nx; cx++) {
+                                const int c = (cz * gv.ny + cy) * gv.nx + cx;
+                                const int ci[3] = {cx, cy, cz};
+                                float clo[3], chi[3];
+                                for (int a = 0; a < 3; a++) {
+                                    // the device computes the cell as floor((p - origin) * inv_cell): widen by the margin
+                                    clo[a] = origin[a] + (float)ci[a] * cell - margin;
+                                    chi[a] = origin[a] + (float)(ci[a] + 1) * cell + margin;
                                 }
-                            }
-                            sorted = lb;
-                            std::sort(sorted.begin(), sorted.end());
-                            for (int L = 0; L < kGridLevels; L++) {
-                                // the cell's reach: every primitive with lb < r is listed, every other is >= r away
-                                float r = plans[L].base;
-                                const int want = std::min(plans[L].min_list, n_bounded);
-                                if (want > 0 && !(sorted[want - 1] < r))
-                                    r = want < n_bounded ? std::nextafter(sorted[want - 1], INFINITY) : INFINITY;
-                                if (n_bounded > plans[L].max_list && sorted[plans[L].max_list] < r) r = sorted[plans[L].max_list];
-                                lv[L].cell_reach[c] = r;
+                                // lower bound of every primitive's distance over the cell
                                 for (int i = 0; i < n_bounded; i++) {
-                                    if (!(lb[i] < r)) continue;
-                                    if (i < (int)gi_sph.size()) {
-                                        lv[L].s_index.push_back(gi_sph[i]);
-                                        lv[L].s_geom.insert(lv[L].s_geom.end(), &g_sph[4 * i], &g_sph[4 * i] + 4);
+                                    const bool is_sphere = i < (int)gi_sph.size();
+                                    double d2 = 0.0;
+                                    if (is_sphere) {
+                                        const float *g = &g_sph[4 * i];
+                                        for (int a = 0; a < 3; a++) {
+                                            const double t = std::max(0.0, std::max((double)clo[a] - g[a], (double)g[a] - chi[a]));
+                                            d2 += t * t;
+                                        }
+                                        lb[i] = (float)(std::sqrt(d2) - fabs((double)g[3])) - margin;
                                     } else {
-                                        const int b = i - (int)gi_sph.size();
-                                        lv[L].b_index.push_back(gi_box[b]);
-                                        lv[L].b_geom.insert(lv[L].b_geom.end(), &g_box[8 * b], &g_box[8 * b] + 8);
+                                        for (int a = 0; a < 3; a++) {
+                                            const double t = std::max(0.0, std::max((double)clo[a] - hi[3 * i + a], (double)lo[3 * i + a] - chi[a]));
+                                            d2 += t * t;
+                                        }
+                                        lb[i] = (float)std::sqrt(d2) - margin;
                                     }
                                 }
-                                lv[L].s_start[c + 1] = (int)lv[L].s_index.size();
-                                lv[L].b_start[c + 1] = (int)lv[L].b_index.size();
+                                sorted = lb;
+                                std::sort(sorted.begin(), sorted.end());
+                                for (int L = 0; L < kGridLevels; L++) {
+                                    // the cell's reach: every primitive with lb < r is listed, every other is >= r away
+                                    float r = plans[L].base;
+                                    const int want = std::min(plans[L].min_list, n_bounded);
+                                    if (want > 0 && !(sorted[want - 1] < r))
+                                        r = want < n_bounded ? std::nextafter(sorted[want - 1], INFINITY) : INFINITY;
+                                    if (n_bounded > plans[L].max_list && sorted[plans[L].max_list] < r) r = sorted[plans[L].max_list];
+                                    lv[L].cell_reach[c] = r;
+                                    for (int i = 0; i < n_bounded; i++)
+                                        if (lb[i] < r) members[L][c].push_back((uint16_t)i);
+                                }
+                            }
+                };
+                {
+                    const int n_threads = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, gv.nz}));
+                    std::vector<std::thread> pool;
+                    for (int t = 0; t < n_threads; t++)
+                        pool.emplace_back(slab, (int)((long long)gv.nz * t / n_threads), (int)((long long)gv.nz * (t + 1) / n_threads));
+                    for (auto &th : pool) th.join();
+                }
+                // phase 2: the lists one after the other, geometry in place
+                for (int L = 0; L < kGridLevels; L++)
+                    for (int c = 0; c < gv.cells; c++) {
+                        for (uint16_t i : members[L][c]) {
+                            if (i < gi_sph.size()) {
+                                lv[L].s_index.push_back(gi_sph[i]);
+                                lv[L].s_geom.insert(lv[L].s_geom.end(), &g_sph[4 * i], &g_sph[4 * i] + 4);
+                            } else {
+                                const int b = i - (int)gi_sph.size();
+                                lv[L].b_index.push_back(gi_box[b]);
+                                lv[L].b_geom.insert(lv[L].b_geom.end(), &g_box[8 * b], &g_box[8 * b] + 8);
                             }
                         }
+                        lv[L].s_start[c + 1] = (int)lv[L].s_index.size();
+                        lv[L].b_start[c + 1] = (int)lv[L].b_index.size();
+                    }
                 e->grid_entries = 0;
                 for (int L = 0; L < kGridLevels; L++) {
                     std::vector<int> cell_rec(4 * (size_t)gv.cells);
