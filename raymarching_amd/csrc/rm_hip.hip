@@ -468,6 +468,7 @@ struct rm_scene {
 
 constexpr int kStatSlots = 32;
 constexpr int kBands = 8;  // row bands of a frame on its way to the host, at most
+constexpr int kDefaultBands = 4;  // measured best at 3840x2160: more bands add launches and copies, fewer overlap less
 constexpr size_t kBandedFramePixels = 4u << 20;  // smaller frames leave in one piece: their bands would each wait for a slow tile
 constexpr int kGridMinPrimitives = 16;  // fewer bounded primitives than this: no spatial index
 constexpr int kGridMaxDim = 48;         // cells per axis at most
@@ -1279,7 +1280,7 @@ int rm_engine_render(rm_engine *e, uint8_t *bgra, size_t pitch_bytes, int32_t mo
     if (int rc_ = sync_view(e)) return rc_;
     if (!e->d_frame) HIP_TRY(dev_alloc(&e->d_frame, (size_t)e->W * e->H * 4));
     // Pinned destinations (rm_host_alloc) take the copy directly at PCIe rate; pageable ones go
-    // through a pinned staging frame and a host memcpy.  Either way the frame leaves in kBands row
+    // through a pinned staging frame and a host memcpy.  Either way a large frame leaves in row
     // bands, bottom band first (the expensive one in scenes with a floor): a band is copied out while
     // the next ones still render, and with a pageable destination the host copies band b out of the
     // staging frame while band b+1 crosses the bus.
@@ -1298,7 +1299,7 @@ int rm_engine_render(rm_engine *e, uint8_t *bgra, size_t pitch_bytes, int32_t mo
     const size_t row_bytes = (size_t)e->W * 4;
     const int strips = (e->H + RM_STRIP_ROWS - 1) / RM_STRIP_ROWS;
     int r0s[kBands], r1s[kBands], n_bands = 0;
-    int want = (size_t)e->W * e->H >= kBandedFramePixels ? kBands : 1;
+    int want = (size_t)e->W * e->H >= kBandedFramePixels ? kDefaultBands : 1;
     if (const char *v = getenv("RM_BANDS")) want = std::max(1, std::min(kBands, atoi(v)));  // tuning aid
     for (int b = want - 1; b >= 0; b--) {  // bottom band first
         const int r0 = (int)((long long)strips * b / want) * RM_STRIP_ROWS;
