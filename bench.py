@@ -35,6 +35,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--fxaa", action="store_true", help="add the FXAA pass to every frame")
     ap.add_argument("--ssaa", action="store_true", help="four rays per pixel (the supersampling the reference carries commented out)")
+    ap.add_argument("--refraction", action="store_true", help="the refraction block the reference carries commented out (engine.rs:196-228)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the CPU baseline leg")
     ap.add_argument("--no-overlap", action="store_true", help="wait for each frame's all-gather before the next render")
@@ -68,7 +69,7 @@ def measured_traffic(width, height):
         return None
 
 
-def cpu_baseline(scene, lightmaps, width, height, budget_s):
+def cpu_baseline(scene, lightmaps, width, height, budget_s, ssaa=False, refraction=False):
     """Times the CPU oracle (test infrastructure) on whole frames of the same workload
     until about `budget_s` seconds of CPU work have been spent (at least 3 frames)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -78,6 +79,9 @@ def cpu_baseline(scene, lightmaps, width, height, budget_s):
     e = oracle.OracleEngine(scene)
     for i in range(e.n_objects):
         e.set_lightmap(i, lightmaps[i])
+    if ssaa:
+        e.set_ssaa(4)
+    e.set_refraction(refraction)
     e.render(width, height, row_step=16, threads=threads)  # warm-up: thread pool, caches
     times = []
     frame = None
@@ -91,7 +95,7 @@ def cpu_baseline(scene, lightmaps, width, height, budget_s):
     e.close()
     times.sort()
     median = times[len(times) // 2]
-    rays = width * height
+    rays = width * height * (4 if ssaa else 1)
     return {
         "value": rays / median / 1e6,
         "unit": "Mrays/s",
@@ -223,7 +227,8 @@ def main():
     eng.input(0, 0, (0.0, 0.0, 0.0), 0)  # first-frame pose (main.rs:78-80,122)
     if args.ssaa:
         eng.set_ssaa(4)
-        args.no_cpu_baseline = True  # parity of this mode is covered by tests/test_render_gpu.py
+    if args.refraction:
+        eng.set_refraction(True)
 
     # Sharding: without FXAA rank r renders the 8-row strips r, r+N, r+2N, ... (even load however
     # the cost is spread over the image); with FXAA it renders one contiguous band plus the few rows
@@ -365,7 +370,7 @@ def main():
     if rank == 0:
         rays = W * H * (4 if args.ssaa else 1)
         ms_per_step = elapsed / args.steps * 1e3
-        counters = load_counters(W, H) if args.workload == "render" and not args.ssaa else None
+        counters = load_counters(W, H) if args.workload == "render" and not args.ssaa and not args.refraction else None
         roofline = None
         if counters is not None:
             band_share = (r1 - r0) / H  # flops are counted for the whole frame; a band is its share by rows
@@ -401,13 +406,14 @@ def main():
             "config": {
                 "workload": (f"default scene {W}x{H}, march + shading + texture + lightmap + reflections" if args.workload == "render"
                              else f"stress scene: 250 spheres and boxes + room, smooth union k=0.08, {W}x{H}, march cap 1024")
-                + (" + FXAA" if args.fxaa else "") + (", 4 rays per pixel" if args.ssaa else ""),
+                + (" + FXAA" if args.fxaa else "") + (", 4 rays per pixel" if args.ssaa else "") + (", refraction on" if args.refraction else ""),
                 "width": W,
                 "height": H,
                 "bands": world,
                 "sharding": "interleaved 8-row strips" if interleaved else "contiguous row bands",
                 "fxaa": bool(args.fxaa),
                 "ssaa": 4 if args.ssaa else 1,
+                "refraction": bool(args.refraction),
                 "map_size": 8,
                 "overlap_gather": world > 1 and not args.no_overlap,
                 "frames_in_flight": in_flight,
@@ -424,7 +430,7 @@ def main():
             result["gathered_frame_equals_single_gpu_render"] = bool(torch.equal(gathered, local))
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N=1 only
             lightmaps = [eng.get_lightmap(i) for i in range(eng.n_objects)]
-            base, cpu_rows = cpu_baseline(scene, lightmaps, W, H, args.cpu_seconds)
+            base, cpu_rows = cpu_baseline(scene, lightmaps, W, H, args.cpu_seconds, args.ssaa, args.refraction)
             result["cpu_baseline"] = base
             if not args.fxaa:
                 # the same frame from the GPU: a parity check at the benchmarked size

@@ -141,6 +141,18 @@ impl Engine {
         })
     }
 
+    /// The parts of the reference that are commented out there: four rays per pixel
+    /// (engine.rs:95-108), four-point normals (objects.rs:142-149), refraction (engine.rs:196-228).
+    pub fn set_ssaa(&mut self, on: bool) -> Result<(), Error> {
+        check(unsafe { sys::rm_engine_set_ssaa(self.handle, if on { 4 } else { 1 }) })
+    }
+    pub fn set_tetrahedral_normals(&mut self, on: bool) -> Result<(), Error> {
+        check(unsafe { sys::rm_engine_set_tetrahedral_normals(self.handle, on as i32) })
+    }
+    pub fn set_refraction(&mut self, on: bool) -> Result<(), Error> {
+        check(unsafe { sys::rm_engine_set_refraction(self.handle, on as i32) })
+    }
+
     pub fn camera_position(&self) -> Result<Vec3, Error> {
         let mut p = [0.0f32; 3];
         check(unsafe { sys::rm_engine_get_camera(self.handle, p.as_mut_ptr()) })?;

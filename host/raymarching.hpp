@@ -198,6 +198,9 @@ class Engine {
     // objects.rs:142-149 (commented out there): four-point normals
     void set_tetrahedral_normals(bool on) { check(rm_engine_set_tetrahedral_normals(handle_, on ? 1 : 0), "set_tetrahedral_normals"); }
 
+    // engine.rs:196-228 (commented out there): reflective objects also refract
+    void set_refraction(bool on) { check(rm_engine_set_refraction(handle_, on ? 1 : 0), "set_refraction"); }
+
     Vec3 camera_position() const {
         Vec3 p;
         check(rm_engine_get_camera(handle_, &p.x), "get_camera");

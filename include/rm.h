@@ -222,6 +222,15 @@ int rm_engine_set_ssaa(rm_engine *engine, int samples);
  * (step 0.0015).  Applies to shading and to the normals of the lightmap precompute. */
 int rm_engine_set_tetrahedral_normals(rm_engine *engine, int on);
 
+/* The refraction block the reference carries commented out in shade_object, engine.rs:196-228
+ * (with Ray::_internal_march, ray.rs:44-56, and Vec3::refract, vector.rs:40-48): on = 1 makes every
+ * hit on an object with reflectivity > 0.001 also cast a ray refracted through the object (index
+ * ratio 2.5; total internal reflection mirrors it) and add the shade of what that ray hits, before
+ * the mirror ray is added.  A hit then has two children: the recursion is cut 16 hits deep, cuts are
+ * counted in RM_STAT_DEPTH_CAP_HITS.  Default 0.  Applies to every render entry point and to
+ * rm_engine_probe_shade. */
+int rm_engine_set_refraction(rm_engine *engine, int on);
+
 /* Optional divergence cap on march iterations (0 = none; the loop of ray.rs:19
  * ends by itself after at most 50/0.001 steps).  Cut marches are counted. */
 int rm_engine_set_march_cap(rm_engine *engine, int max_steps);

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -755,6 +756,12 @@ struct Engine {
     int map_size = 8;
     float smooth_k = 0.0f;  // EXTENSION, see Ray::smooth_k
     int ssaa = 1;           // 4 = the four-ray supersampling of engine.rs:95-108 (commented out there)
+    // EXTENSION switch: the refraction block of engine.rs:196-228 (commented out there).  With it a
+    // reflective hit has two children, so the recursion is a tree; it is cut where it is REFRACTION_MAX_DEPTH
+    // hits deep (the reference has no limit) and the cuts are counted in `refraction_depth_cuts`.
+    bool refraction = false;
+    static constexpr uint64_t REFRACTION_MAX_DEPTH = 16;
+    mutable std::atomic<uint64_t> refraction_depth_cuts{0};
     mutable std::vector<uint64_t> fold_order;
     const std::vector<uint64_t> *order() const {
         if (fold_order.size() != objects.size()) {
@@ -814,6 +821,26 @@ struct Engine {
         float shade = shadow.smooth_shadow_march(objects, obj_index, distance_to_light, 16.0f);
 
         Colour final_colour = ambient + object_colour * (shade * (diffuse + specular));
+
+        if (refraction && object_mat.reflectivity > 1e-3f) {
+            if (depth >= REFRACTION_MAX_DEPTH) {
+                refraction_depth_cuts++;
+                return final_colour;
+            }
+            // engine.rs:199-226
+            const float ior = 2.5f;
+            Vec3 refraction_vector = direction.refract(n, 1.0f / ior);
+            Ray enter_ray{position + refraction_vector * (3.0f * SMALL_DISTANCE), refraction_vector};
+            enter_ray.internal_march(object);
+            Vec3 exit_n = object.calculate_normal(enter_ray.position);
+            Vec3 exit_direction = refraction_vector.refract(-exit_n, ior);
+            if (exit_direction.mag_sqd() == 0.0f) exit_direction = refraction_vector.reflect(-exit_n);  // total internal reflection
+            Ray exit_ray{enter_ray.position, exit_direction};
+            exit_ray.smooth_k = smooth_k;
+            exit_ray.order = order();
+            uint64_t refr_hit = exit_ray.march(objects, obj_index);
+            if (refr_hit != NONE) final_colour += shade_object(refr_hit, exit_ray.position, exit_ray.direction, depth + 1);
+        }
 
         if (object_mat.reflectivity > 1e-3f) {
             float fresnel = powi5(rs_clamp(1.0f - n.dot(-direction), 0.0f, 1.0f));
@@ -1217,6 +1244,17 @@ int orc_add_box(void *h, const float *pos, const float *half, const float *mat, 
 }
 void orc_set_smooth_union(void *h, float k) { static_cast<Engine *>(h)->smooth_k = k; }
 void orc_set_ssaa(void *h, int samples) { static_cast<Engine *>(h)->ssaa = samples; }
+void orc_set_refraction(void *h, int on) { static_cast<Engine *>(h)->refraction = on != 0; }
+uint64_t orc_refraction_depth_cuts(void *h) { return static_cast<Engine *>(h)->refraction_depth_cuts.load(); }
+// ray.rs:44-56 on a sphere: pos is moved to where the march leaves it
+void orc_kat_internal_march(const float *centre, float radius, float *pos, const float *dir) {
+    Sphere s(8);
+    s.position = Vec3(centre[0], centre[1], centre[2]);
+    s.radius = radius;
+    Ray r{Vec3(pos[0], pos[1], pos[2]), Vec3(dir[0], dir[1], dir[2])};
+    r.internal_march(s);
+    for (int i = 0; i < 3; i++) pos[i] = r.position.l[i];
+}
 void orc_set_tetrahedral_normals(void *h, int on) {
     for (auto &o : static_cast<Engine *>(h)->objects) o->tetra_normals = on != 0;
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "rm_engine_probe_shade": (c_int, [c_void_p, c_int, POINTER(c_int32), POINTER(c_float), POINTER(c_float), POINTER(c_float)]),
     "rm_engine_set_ssaa": (c_int, [c_void_p, c_int]),
     "rm_engine_set_tetrahedral_normals": (c_int, [c_void_p, c_int]),
+    "rm_engine_set_refraction": (c_int, [c_void_p, c_int]),
     "rm_engine_set_march_cap": (c_int, [c_void_p, c_int]),
     "rm_engine_get_stats": (c_int, [c_void_p, POINTER(c_uint64)]),
     "rm_engine_reset_stats": (c_int, [c_void_p]),

@@ -108,6 +108,14 @@ RM_DEV V3 normalized(V3 a) {
 }
 RM_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }  // vector.rs:32
 RM_DEV V3 reflect(V3 v, V3 n) { return v - n * (2.0f * dot(n, v)); }          // vector.rs:38
+// vector.rs:40-48; `ior` is the ratio of the two refractive indices.  Only the refraction block of
+// engine.rs:196-228 (commented out in the reference) calls it.
+RM_DEV V3 refract(V3 v, V3 n, float ior) {
+    const float c = dot(v, n);
+    const float k = 1.0f - (ior * ior) * (1.0f - c * c);
+    if (k < 0.0f) return V3{0.0f, 0.0f, 0.0f};
+    return v * ior - n * (ior * c + sqrt_rn(k));
+}
 
 // Rust f32::clamp keeps a NaN input; f32::min/max drop a NaN operand.
 RM_DEV float rs_clamp(float x, float lo, float hi) {
@@ -986,6 +994,102 @@ RM_DEV V3 cast_sight_ray(const SC &sc, const SceneView &sv, V3 pos, V3 dir) {
         colour = f + emul(colour, oc) * stk[depth][6];  // engine.rs:239-240
     }
     return colour;
+}
+
+// ray.rs:44-56: walks a ray that starts inside an object to where it leaves it, by the object's own
+// distance alone, 20 steps at most.
+RM_DEV V3 internal_march(int type, const Geom &g, V3 pos, V3 dir) {
+    for (int it = 0; it < 20; it++) {
+        const float d = sdf_eval(type, g, pos);
+        if (d > SMALL_DISTANCE) break;
+        pos = pos + dir * fabsf(d);
+    }
+    return pos;
+}
+
+// cast_sight_ray with the refraction block of engine.rs:196-228 switched on (the reference carries
+// it commented out).  A reflective hit then has two children - the ray refracted through the object
+// (index ratio 2.5, shaded only if it hits something) and the mirror ray - so the recursion is a tree.
+// It is walked depth first with one frame per open hit: the refracted subtree is finished and added
+// first, then the mirror subtree, which is the order the recursion adds them in.  `first_hit` >= 0
+// starts at shade_object for that object at `pos` instead of marching (engine.rs:147).
+constexpr float REFRACTION_IOR = 2.5f;
+template <class SC>
+RM_DEV V3 cast_sight_tree(const SC &sc, const SceneView &sv, V3 pos, V3 dir, int first_hit = -1) {
+    struct Frame {
+        V3 acc, oc;       // the hit's colour so far (engine.rs:194, then :225 added); its object colour
+        V3 rpos, rdir;    // the mirror ray, cast once the refracted subtree is done (engine.rs:235-237)
+        float kk;         // engine.rs:240
+        int refracted;    // 0: the refracted subtree is being walked; 1: the mirror subtree
+    };
+    Frame stk[MAX_DEPTH];
+    int depth = 0;
+    int ignore = -1;          // engine.rs:222: the refracted ray leaves out the object it comes from
+    bool sky_on_miss = true;  // engine.rs:138 for sight rays; a refracted ray that hits nothing adds nothing (:224)
+    for (;;) {
+        int idx = first_hit;
+        if (idx < 0) {
+            int steps;
+            bool capped;
+            idx = march(sc, pos, dir, ignore, sv.march_cap, steps, capped);
+            if (capped) atomicAdd(&sv.stats[1], 1ULL);
+        }
+        first_hit = -1;
+        bool have = true;
+        V3 val = v3(sv.sky[0], sv.sky[1], sv.sky[2]);
+        if (idx < 0) {
+            have = sky_on_miss;
+        } else {
+            const ShadeResult r = shade_local(sc, sv, idx, pos, dir);
+            val = r.final_colour;
+            if (r.reflectivity > 1e-3f) {
+                if (depth >= MAX_DEPTH) {
+                    atomicAdd(&sv.stats[0], 1ULL);
+                } else {
+                    const Geom g = sv.geom[idx];
+                    const int type = sv.shade[idx].type;
+                    const V3 in = refract(dir, r.n, 1.0f / REFRACTION_IOR);                          // engine.rs:200
+                    const V3 exit_pos = internal_march(type, g, pos + in * (3.0f * SMALL_DISTANCE), in);  // :201-206
+                    const V3 exit_n = calculate_normal(type, g, exit_pos, sv.tetra_normals != 0);   // :208
+                    V3 out = refract(in, -exit_n, REFRACTION_IOR);                                   // :209
+                    if (mag_sqd(out) == 0.0f) out = reflect(in, -exit_n);                            // :213-215
+                    const float fresnel = powi5(rs_clamp(1.0f - dot(r.n, -dir), 0.0f, 1.0f));        // :233
+                    const V3 rv = reflect(dir, r.n);
+                    Frame &f = stk[depth++];
+                    f.acc = r.final_colour;
+                    f.oc = r.object_colour;
+                    f.rpos = pos + ((rv * 3.0f) * SMALL_DISTANCE);  // :237
+                    f.rdir = rv;
+                    f.kk = rs_clamp(fresnel + r.reflectivity, 0.0f, 1.0f);
+                    f.refracted = 0;
+                    pos = exit_pos;
+                    dir = out;
+                    ignore = idx;
+                    sky_on_miss = false;
+                    continue;
+                }
+            }
+        }
+        // a subtree is finished: hand its colour to the open hits above it
+        bool done = true;
+        while (depth > 0) {
+            Frame &f = stk[depth - 1];
+            if (f.refracted == 0) {
+                if (have) f.acc = f.acc + val;  // engine.rs:225
+                f.refracted = 1;
+                pos = f.rpos;
+                dir = f.rdir;
+                ignore = -1;
+                sky_on_miss = true;
+                done = false;
+                break;
+            }
+            val = f.acc + emul(val, f.oc) * f.kk;  // engine.rs:239-240
+            have = true;
+            depth--;
+        }
+        if (done) return val;
+    }
 }
 
 // engine.rs:24-32

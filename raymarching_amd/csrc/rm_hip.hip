@@ -161,6 +161,32 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_ssaa_kernel(const Render
     *reinterpret_cast<unsigned *>(a.out + (size_t)out_row * a.pitch + (size_t)x * 4) = px;
 }
 
+// The frame with the refraction block of engine.rs:196-228 switched on; `samples` = 4 adds the
+// supersampling of engine.rs:95-108.  A kernel of its own: the tree walk needs more registers and
+// private memory than the plain frame should pay for.
+template <class G>
+__global__ __launch_bounds__(BLOCK_THREADS) void render_tree_kernel(const RenderArgs a, int samples, const G g) {
+    int x, y_inv, out_row;
+    tile_pixel(a, x, y_inv, out_row);
+    if (x >= a.pose.W || y_inv >= a.row_end) return;
+    const V3 dir = pixel_direction(a.pose, x, y_inv);
+    const V3 cam = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
+    V3 colour;
+    if (samples == 4) {
+        const float ox = 0.5f / (float)a.pose.W, oy = 0.5f / (float)a.pose.H;
+        V3 sum = v3(0.0f, 0.0f, 0.0f);
+        for (int i = 0; i < 4; i++) {
+            const V3 off = i == 0 ? v3(ox, 0.0f, 0.0f) : i == 1 ? v3(-ox, 0.0f, 0.0f) : i == 2 ? v3(0.0f, oy, 0.0f) : v3(0.0f, -oy, 0.0f);
+            const V3 c = cast_sight_tree(acc_of(g), *a.sv, cam, normalized(dir + off));
+            sum = i == 0 ? c : sum + c;
+        }
+        colour = sum / 4.0f;
+    } else {
+        colour = cast_sight_tree(acc_of(g), *a.sv, cam, dir);
+    }
+    *reinterpret_cast<unsigned *>(a.out + (size_t)out_row * a.pitch + (size_t)x * 4) = pack_pixel(colour, a.pose.exposure);
+}
+
 // Primary march only: hit object, iteration count, final position.
 template <class G>
 __global__ __launch_bounds__(BLOCK_THREADS) void trace_kernel(const RenderArgs a, int *hit, int *steps_out,
@@ -194,6 +220,13 @@ __global__ void probe_shade_kernel(const SceneView *svp, int n, const int *obj, 
     V3 d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
     int idx = obj[i];
     auto body = [&](auto sc) {
+        if (sv.refraction) {
+            const V3 c = cast_sight_tree(sc, sv, p, d, idx);
+            out[3 * i] = c.x;
+            out[3 * i + 1] = c.y;
+            out[3 * i + 2] = c.z;
+            return;
+        }
         ShadeResult r = shade_local(sc, sv, idx, p, d);
         V3 c = r.final_colour;
         if (r.reflectivity > 1e-3f) {
@@ -486,6 +519,7 @@ struct rm_engine {
     int march_cap = 0;
     bool ssaa = false;  // four rays per pixel (engine.rs:95-108)
     bool tetra_normals = false;  // objects.rs:142-149
+    bool refraction = false;     // engine.rs:196-228
     size_t grid_entries = 0;  // list entries of the spatial index (0 = none)
 
     // device-resident scene
@@ -548,6 +582,7 @@ struct rm_engine {
         for (int i = 0; i < 3; i++) sv.sky[i] = (sky8[i] / 255.0f) * (sky8[i] / 255.0f);
         sv.march_cap = march_cap;
         sv.tetra_normals = tetra_normals ? 1 : 0;
+        sv.refraction = refraction ? 1 : 0;
         sv.stats = d_stats;
         return sv;
     }
@@ -1241,7 +1276,9 @@ int rm_engine_render_rows_device(rm_engine *e, void *d_bgra, size_t pitch_bytes,
     if (int rc_ = sync_view(e)) return rc_;
     dim3 grid;
     RenderArgs a = make_render_args(e, d_bgra, pitch_bytes, row_begin, row_end, grid);
-    if (e->ssaa)
+    if (e->refraction)
+        RM_LAUNCH(render_tree_kernel, e, grid, dim3(BLOCK_THREADS), a, e->ssaa ? 4 : 1);
+    else if (e->ssaa)
         RM_LAUNCH(render_ssaa_kernel, e, grid, dim3(BLOCK_THREADS), a);
     else
         RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);
@@ -1262,7 +1299,9 @@ int rm_engine_render_strips_device(rm_engine *e, void *d_bgra, size_t pitch_byte
     a.blocks_y = n_strips;
     a.tile_row_stride = strip_stride;
     grid = dim3((unsigned)(a.blocks_x * a.blocks_y), 1, 1);
-    if (e->ssaa)
+    if (e->refraction)
+        RM_LAUNCH(render_tree_kernel, e, grid, dim3(BLOCK_THREADS), a, e->ssaa ? 4 : 1);
+    else if (e->ssaa)
         RM_LAUNCH(render_ssaa_kernel, e, grid, dim3(BLOCK_THREADS), a);
     else
         RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);
@@ -1610,6 +1649,13 @@ int rm_engine_set_ssaa(rm_engine *e, int samples) {
 int rm_engine_set_tetrahedral_normals(rm_engine *e, int on) {
     if (!e) return fail(RM_ERR_INVALID, "NULL engine");
     e->tetra_normals = on != 0;
+    e->view_dirty = true;
+    return RM_OK;
+}
+
+int rm_engine_set_refraction(rm_engine *e, int on) {
+    if (!e) return fail(RM_ERR_INVALID, "NULL engine");
+    e->refraction = on != 0;
     e->view_dirty = true;
     return RM_OK;
 }

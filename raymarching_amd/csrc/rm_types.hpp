@@ -128,6 +128,7 @@ struct SceneView {
     float sky[3];
     int march_cap;  // 0 = none
     int tetra_normals;  // 1 = the four-point normal of objects.rs:142-149 (commented out there)
+    int refraction;     // 1 = the refraction block of engine.rs:196-228 (commented out there)
     unsigned long long *stats;
 };
 

@@ -222,6 +222,10 @@ class Engine:
         """objects.rs:142-149: the four-point normal instead of central differences."""
         _lib.check(self.lib.rm_engine_set_tetrahedral_normals(self.handle, 1 if on else 0), "rm_engine_set_tetrahedral_normals")
 
+    def set_refraction(self, on):
+        """engine.rs:196-228: reflective objects also pass a refracted ray (index ratio 2.5)."""
+        _lib.check(self.lib.rm_engine_set_refraction(self.handle, 1 if on else 0), "rm_engine_set_refraction")
+
     def set_march_cap(self, max_steps):
         _lib.check(self.lib.rm_engine_set_march_cap(self.handle, max_steps), "rm_engine_set_march_cap")
 

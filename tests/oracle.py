@@ -53,6 +53,10 @@ def load(counting=False):
     lib.orc_set_smooth_union.argtypes = [c_void_p, c_float]
     lib.orc_set_ssaa.argtypes = [c_void_p, c_int]
     lib.orc_set_tetrahedral_normals.argtypes = [c_void_p, c_int]
+    lib.orc_set_refraction.argtypes = [c_void_p, c_int]
+    lib.orc_refraction_depth_cuts.restype = ctypes.c_uint64
+    lib.orc_refraction_depth_cuts.argtypes = [c_void_p]
+    lib.orc_kat_internal_march.argtypes = [_F, c_float, _F, _F]
     lib.orc_kat_smooth_min.restype = c_float
     lib.orc_kat_smooth_min.argtypes = [c_float, c_float, c_float]
     lib.orc_set_light.argtypes = [c_void_p, _F, c_float]
@@ -144,6 +148,12 @@ class OracleEngine:
 
     def set_tetrahedral_normals(self, on):
         self.lib.orc_set_tetrahedral_normals(self.handle, 1 if on else 0)
+
+    def set_refraction(self, on):
+        self.lib.orc_set_refraction(self.handle, 1 if on else 0)
+
+    def refraction_depth_cuts(self):
+        return int(self.lib.orc_refraction_depth_cuts(self.handle))
 
     def set_light(self, pos, intensity):
         self.lib.orc_set_light(self.handle, _fa(pos), intensity)

@@ -323,6 +323,37 @@ def test_refract_dead_code(lib):
     assert tuple(out) == (0.0, -1.0, 0.0) or (abs(out[0]) < 1e-7 and abs(out[1] + 1.0) < 1e-6)
 
 
+def test_internal_march_leaves_the_sphere(lib):
+    # ray.rs:44-56: from just inside the near side, straight through the centre, the steps double up
+    # to the centre and then halve towards the far side, where the march stalls on the surface
+    pos = F3(0.0, 0.0, -0.997)
+    lib.orc_kat_internal_march(F3(0.0, 0.0, 0.0), 1.0, pos, F3(0.0, 0.0, 1.0))
+    assert pos[0] == 0.0 and pos[1] == 0.0 and abs(pos[2] - 1.0) < 1e-3
+    # a ray that starts outside by more than SMALL_DISTANCE does not move
+    pos = F3(0.0, 0.0, -1.5)
+    lib.orc_kat_internal_march(F3(0.0, 0.0, 0.0), 1.0, pos, F3(0.0, 0.0, 1.0))
+    assert tuple(pos) == (0.0, 0.0, -1.5)
+
+
+def test_refraction_mode_of_the_oracle(lib):
+    """engine.rs:196-228 switched on: only pixels that show a reflective object (the two spheres,
+    directly or in a mirror image) change, and the added light never darkens a pixel's linear colour
+    (checked on the encoded bytes, which are monotonic in it)."""
+    sc = default_scene()
+    ora = oracle.OracleEngine(sc)
+    ora.compute_lightmaps(1)
+    w, h = 160, 120
+    base = ora.render(w, h, 0, 0, (0.0, 0.0, 0.0), 0)
+    hit, _, _ = ora.trace_primary(w, h)
+    ora.set_refraction(True)
+    glass = ora.render(w, h, 0, 0, (0.0, 0.0, 0.0), 0)
+    changed = (glass != base).any(axis=-1)
+    assert changed.any() and not changed[hit > 1].any()
+    assert (glass.astype(int) >= base.astype(int)).all()
+    assert ora.refraction_depth_cuts() == 0
+    ora.close()
+
+
 def _fxaa_reference_pixel(img, x, y):
     """fxaa.txt:15-133 for one pixel in numpy float32, written independently of the oracle."""
     W = img.shape[1]

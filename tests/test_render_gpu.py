@@ -217,6 +217,49 @@ def test_tetrahedral_normals(scene):
     eng.close()
 
 
+def test_refraction(scene, oracle_lightmaps):
+    """The refraction block the reference carries commented out (engine.rs:196-228, ray.rs:44-56,
+    vector.rs:40-48): frames of the default scene (both spheres refract), one of them supersampled,
+    and shade_object at points on the spheres.  No recursion is cut on either side, so the frames are
+    the unbounded recursion's."""
+    from raymarching_amd import Engine
+
+    w, h = 320, 240
+    lm, _ = oracle_lightmaps
+    ora = make_oracle(scene, lm[-1])
+    ora.set_refraction(True)
+    eng = Engine(scene, w, h)
+    for i in range(eng.n_objects):
+        eng.set_lightmap(i, lm[-1][i])
+    plain = eng.render(None, 0, 0, (0.0, 0.0, 0.0), 0)
+    eng.set_refraction(True)
+    poses = [(0, 0, (0.0, 0.0, 0.0), 0), (310, 120, (0.9, -0.1, 1.6), 3), (-420, 60, (-0.6, 0.2, 1.1), -2)]
+    for k, pose in enumerate(poses):
+        got, ref = eng.render(None, *pose), ora.render(w, h, *pose)
+        mx, exact = assert_frames_match(got, ref, f"refraction pose {k}")
+        print(f"refraction pose {k}: max|d|={mx} exact={exact:.5%}")
+        if k == 0:
+            assert (got != plain).any(axis=-1).mean() > 0.02  # the spheres look different with it
+    eng.set_ssaa(4)
+    ora.set_ssaa(4)
+    mx, exact = assert_frames_match(eng.render(None, *poses[1]), ora.render(w, h, *poses[1]), "refraction, supersampled")
+    print(f"refraction + ssaa: max|d|={mx} exact={exact:.5%}")
+    ora.set_ssaa(1)
+
+    # shade_object on sphere points seen from the last pose
+    hit, _, pos = ora.trace_primary(w, h)
+    ys, xs = np.nonzero(hit <= 1)
+    pick = np.random.default_rng(5).choice(len(ys), 200, replace=False)
+    objs, pts = hit[ys[pick], xs[pick]].astype(np.int32), pos[ys[pick], xs[pick]]
+    dirs = pts - np.asarray(ora.camera_position, dtype=np.float32)
+    dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+    got = eng.probe_shade(objs, pts, dirs)
+    ref = np.stack([ora.shade(o, p, d) for o, p, d in zip(objs, pts, dirs)])
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6)
+    assert eng.stats()["depth_cap_hits"] == 0 and ora.refraction_depth_cuts() == 0
+    eng.close()
+
+
 def test_frame_sequence_with_recorded_input(scene, oracle_lightmaps):
     """A recorded input trace (mouse look, WASD movement, scroll zoom; main.rs:105-138) played
     through the pipelined rm_engine_render_async path: every frame and the final camera match the

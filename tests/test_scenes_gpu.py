@@ -79,11 +79,13 @@ SCENES = {
 }
 
 
-def _compare(scene, w=W, h=H, pose=(0, 0, (0.0, 0.0, 0.0), 0), lightmaps=True):
+def _compare(scene, w=W, h=H, pose=(0, 0, (0.0, 0.0, 0.0), 0), lightmaps=True, refraction=False):
     from raymarching_amd import Engine
 
     eng = Engine(scene, w, h)
     ora = make_oracle(scene)
+    eng.set_refraction(refraction)
+    ora.set_refraction(refraction)
     if not lightmaps:
         # no precompute: fill every lightmap with the same smooth, nowhere-zero pattern on both sides
         # (with empty maps the reference's resampling walks off the map and aborts, objects.rs:78-113)
@@ -108,6 +110,7 @@ def _compare(scene, w=W, h=H, pose=(0, 0, (0.0, 0.0, 0.0), 0), lightmaps=True):
     got = eng.render(None, *pose)
     ref = ora.render(w, h, *pose)
     st = eng.stats()
+    st["oracle_depth_cuts"] = ora.refraction_depth_cuts()
     eng.close()
     return got, ref, st, hit_o
 
@@ -126,6 +129,29 @@ def test_scene_tiers(name):
         assert (hit < 0).any(), "no primary ray reached the sky"
     else:
         assert st["lightmap_oob"] == 0
+
+
+def _mirror_floor():
+    base = default_scene()
+    objs = list(base.objects)
+    objs[2] = YPlane(-2.0, 1.0, GLOSSY, SOFT_GRAY, objs[2].texture)
+    return Scene(objects=objs, camera_position=base.camera_position, light=base.light)
+
+
+@pytest.mark.parametrize("name", ["tier_b", "large_small", "boxes", "grid_sparse_open", "mirror_floor"])
+def test_refraction_in_scene_tiers(name):
+    """The refraction block (engine.rs:196-228) over the other scene tiers: refracting boxes (their
+    own distance walks the ray out, ray.rs:44-56), many small refracting spheres through the spatial
+    index, and a refracting plane, which has no far side - the walk runs its 20 doubling steps into
+    the half space and the ray goes on from there."""
+    scene = _mirror_floor() if name == "mirror_floor" else SCENES[name]()
+    has_plane = any(isinstance(o, (Plane, Box)) for o in scene.objects)
+    got, ref, st, _ = _compare(scene, 240, 180, pose=(60, 30, (0.1, 0.0, 0.3), 0), lightmaps=not has_plane, refraction=True)
+    mx, exact = assert_frames_match(got, ref, name)
+    print(f"refraction, {name}: max|d|={mx} exact={exact:.5%} caps={st}")
+    # both sides cut the tree 16 hits deep and count the cuts (a ray caught between a box and the
+    # mirror next to it gets there in the "boxes" scene)
+    assert st["depth_cap_hits"] == st["oracle_depth_cuts"]
 
 
 def test_stress_scene_250_spheres():
