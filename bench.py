@@ -40,8 +40,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the CPU baseline leg")
     ap.add_argument("--no-overlap", action="store_true", help="wait for each frame's all-gather before the next render")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="1 = frames one after the other; 2 = consecutive frames on two streams, so that the long-running "
-                         "tiles at the end of one frame overlap the start of the next (default: 1 on one GPU, 2 on several)")
+                    help="1 = frames one after the other; n = consecutive frames on n streams, so that the long-running "
+                         "tiles at the end of one frame overlap the start of the next ones (default: 1 on one GPU, 3 on several)")
     ap.add_argument("--workload", choices=["render", "radiosity", "stress"], default="render",
                     help="render: the headline frame benchmark; radiosity: Engine::compute_lightmaps, patch-sharded; "
                     "stress: 256 mixed primitives with smooth unions at 7680x4320, march cap 1024")
@@ -243,21 +243,25 @@ def main():
     else:
         band_h = (H + world - 1) // world
         r0, r1 = band_rows(H, rank, world)
-    # double-buffered so that the gather of frame f overlaps the render of frame f+1
-    bands = [torch.zeros((band_h, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
-    frames = [torch.zeros((world * band_h, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
-    final = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)] if interleaved else None
-    fx_srcs = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)] if args.fxaa else None
-
-    kernel_events = []
-    in_flight = args.frames_in_flight or (2 if world > 1 else 1)
+    # A rank's share of a frame is bounded by its few slowest tiles, not by its size, so several
+    # frames are kept in flight: measured on one GPU, an eighth of the 3840x2160 frame takes 0.132 ms
+    # alone, 0.066 ms per frame with two in flight and 0.045 ms with three (0.039 would be an eighth
+    # of the whole frame's time); a fourth stream gains nothing.
+    in_flight = args.frames_in_flight or (3 if world > 1 else 1)
     if args.no_overlap:
         in_flight = 1
-    # every frame of parity b is rendered, gathered and put in order on streams[b]
+    n_buf = max(in_flight, 2)  # one set of buffers per frame in flight (two at least: gather f beside render f+1)
+    bands = [torch.zeros((band_h, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
+    frames = [torch.zeros((world * band_h, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
+    final = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if interleaved else None
+    fx_srcs = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if args.fxaa else None
+
+    kernel_events = []
+    # frame s is rendered, gathered and put in order on streams[s % in_flight]
     streams = [stream] + [torch.cuda.Stream() for _ in range(in_flight - 1)]
 
     def render_band(buf, timed):
-        fx_src = fx_srcs[0 if buf is bands[0] else 1] if args.fxaa else None  # one per frame in flight
+        fx_src = fx_srcs[next(i for i, b in enumerate(bands) if b is buf)] if args.fxaa else None  # one per frame in flight
         stream = torch.cuda.current_stream()
         eng.set_stream(stream.cuda_stream)
         if timed:
@@ -323,14 +327,15 @@ def main():
             if pending is not None:
                 finish(pending)
             return
-        # Two frames in flight: frame s lives on streams[s & 1] from its render to the re-ordering of
-        # its gathered strips, so the render of frame s+1 runs beside the tail of frame s.  Buffers of
-        # parity b are reused by frame s+2 on the same stream, after frame s has been finished there.
-        pending = [None, None]
+        # Several frames in flight: frame s lives on streams[s % in_flight] from its render to the
+        # re-ordering of its gathered strips, so the renders of the next frames run beside the tail of
+        # frame s.  Buffer set b is reused by frame s + in_flight on the same stream, after frame s has
+        # been finished there.
+        pending = [None] * in_flight
         for st in streams:
             st.wait_stream(stream)
         for s in range(steps):
-            b = s & 1
+            b = s % in_flight
             with torch.cuda.stream(streams[b]):
                 if pending[b] is not None:
                     finish(pending[b])
@@ -338,10 +343,12 @@ def main():
                 render_band(bands[b], timed)
                 if world > 1:
                     pending[b] = (start_gather(frames[b].view(-1), bands[b].view(-1)), b)
-        for b in ((steps & 1), 1 - (steps & 1)):  # older frame first
+        for s in range(max(steps - in_flight, 0), steps):  # oldest frame first
+            b = s % in_flight
             if pending[b] is not None:
                 with torch.cuda.stream(streams[b]):
                     finish(pending[b])
+                pending[b] = None
         for st in streams[1:]:
             stream.wait_stream(st)
         eng.set_stream(stream.cuda_stream)
@@ -367,6 +374,7 @@ def main():
     stats = eng.stats()
 
     result = None
+    last_buf = (args.steps - 1) % in_flight if in_flight > 1 else (args.steps - 1) & 1  # where the last frame landed
     if rank == 0:
         rays = W * H * (4 if args.ssaa else 1)
         ms_per_step = elapsed / args.steps * 1e3
@@ -423,7 +431,7 @@ def main():
         }
         if world > 1 and not args.fxaa:
             # the gathered frame against the same frame rendered whole on this GPU (bit for bit)
-            gathered = (final if interleaved else frames)[(args.steps - 1) & 1][:H]
+            gathered = (final if interleaved else frames)[last_buf][:H]
             local = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
             eng.render_rows_device(local.data_ptr(), 0, H)
             torch.cuda.synchronize()
@@ -434,7 +442,7 @@ def main():
             result["cpu_baseline"] = base
             if not args.fxaa:
                 # the same frame from the GPU: a parity check at the benchmarked size
-                full = (final if interleaved else frames)[(args.steps - 1) & 1] if world > 1 else None
+                full = (final if interleaved else frames)[last_buf] if world > 1 else None
                 if full is None:
                     full = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
                     eng.render_rows_device(full.data_ptr(), 0, H)
