@@ -384,78 +384,98 @@ __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0
 
 // ---- FXAA (fxaa.txt:1-135, out of place) -------------------------------------
 
-// b / 255.0f for a byte b, correctly rounded, in three operations instead of a
-// full division: one Newton step on b * (1/255) with fused residuals.  Checked
-// against the IEEE quotient for all 256 inputs (tests/test_host.py).
-__device__ __forceinline__ float fx_unorm(unsigned b) {
+// b / 255.0f for a byte b, correctly rounded, in two operations instead of a full division:
+// 1/255 = c + c_lo with c the nearest float, and fma(b, c, b * c_lo) rounds b * c (exact inside the
+// fused operation) plus a correction that is right to 2^-24 of itself - b/255 is never that close to
+// a rounding boundary.  Checked against the IEEE quotient for all 256 inputs (tests/test_host.py).
+__device__ __forceinline__ float fx_unorm(float b) {
     const float c = 1.0f / 255.0f;
-    const float x = (float)b;
-    const float q = x * c;
-    const float r = __builtin_fmaf(-q, 255.0f, x);
-    return __builtin_fmaf(r, c, q);
+    const float c_lo = (float)(1.0 / 255.0 - (double)c);
+    return __builtin_fmaf(b, c, b * c_lo);
 }
-__device__ __forceinline__ void fx_load(const unsigned char *src, size_t i, float c[3]) {
-    unsigned px = *reinterpret_cast<const unsigned *>(src + i * 4);
-    c[0] = fx_unorm(px & 255u);
-    c[1] = fx_unorm((px >> 8) & 255u);
-    c[2] = fx_unorm((px >> 16) & 255u);
+__device__ __forceinline__ void fx_unpack(unsigned px, float c[3]) {
+    c[0] = fx_unorm((float)(px & 255u));
+    c[1] = fx_unorm((float)((px >> 8) & 255u));
+    c[2] = fx_unorm((float)((px >> 16) & 255u));
 }
 __device__ __forceinline__ float fx_luma(const float c[3]) { return (0.299f * c[0] + 0.587f * c[1]) + 0.114f * c[2]; }
-// `as usize` of a rounded offset: negative and NaN become 0
-__device__ __forceinline__ int fx_off(float o) { return sat_i32(roundf(o)); }
-__device__ __forceinline__ unsigned fx_u8(float f) {
-    if (!(f == f) || f <= 0.0f) return 0u;
-    if (f >= 255.0f) return 255u;
-    return (unsigned)f;
+// `round() as usize` of a tap offset (fxaa.txt:90-97): half away from zero, negative becomes 0.  The
+// offsets here are finite and at most 4 in size, so o - floor(o) is exact and the rounding is
+// floor(o) plus one when that fraction reaches a half; whatever a negative offset gives is <= 0.
+__device__ __forceinline__ int fx_off(float o) {
+    const float fl = floorf(o);
+    const int r = (int)fl + ((o - fl) >= 0.5f ? 1 : 0);
+    return max(r, 0);
 }
+// `(255.0 * c) as u8` (fxaa.txt:131-133): truncation; the values are averages of bytes over 255, so
+// they lie in [0, 255] and the clamp never binds
+__device__ __forceinline__ unsigned fx_u8(float f) { return (unsigned)min(max((int)f, 0), 255); }
 
 __global__ __launch_bounds__(256) void fxaa_kernel(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst,
                                                    int W, int H, int row_begin, int row_end) {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y_inv = row_begin + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y_inv = row_begin + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y_inv >= row_end) return;
-    size_t i = (size_t)y_inv * W + x;
-    unsigned centre = *reinterpret_cast<const unsigned *>(src + i * 4);
+    // byte offsets into the frame fit 32 bits (the host checks the frame size), so every tap is the
+    // base pointer plus a 32-bit offset: no 64-bit address arithmetic per fetch
+    const auto in = [src](unsigned pixel) { return *reinterpret_cast<const unsigned *>(src + (pixel << 2)); };
+    const unsigned i = (unsigned)y_inv * (unsigned)W + (unsigned)x;
+    const unsigned centre = in(i);
     if (x < 4 || x >= W - 4 || y_inv < 4 || y_inv >= H - 4) {  // fxaa.txt:7-8 leaves the border untouched
-        *reinterpret_cast<unsigned *>(dst + i * 4) = centre;
+        *reinterpret_cast<unsigned *>(dst + (i << 2)) = centre;
         return;
     }
     float nw[3], ne[3], sw[3], se[3], m[3];
-    fx_load(src, i - W - 1, nw);
-    fx_load(src, i - W + 1, ne);
-    fx_load(src, i + W - 1, sw);
-    fx_load(src, i + W + 1, se);
-    fx_load(src, i, m);
-    float lNW = fx_luma(nw), lNE = fx_luma(ne), lSW = fx_luma(sw), lSE = fx_luma(se), lM = fx_luma(m);
-    float lmin = rs_min(lM, rs_min(rs_min(lNW, lNE), rs_min(lSW, lSE)));
-    float lmax = rs_max(lM, rs_max(rs_max(lNW, lNE), rs_max(lSW, lSE)));
+    fx_unpack(in(i - W - 1), nw);
+    fx_unpack(in(i - W + 1), ne);
+    fx_unpack(in(i + W - 1), sw);
+    fx_unpack(in(i + W + 1), se);
+    const float lNW = fx_luma(nw), lNE = fx_luma(ne), lSW = fx_luma(sw), lSE = fx_luma(se);
     float d0 = -((lNW + lNE) - (lSW + lSE));
     float d1 = (lNW + lSW) - (lNE + lSE);
-    float reduce = rs_max((((lNW + lNE) + lSW) + lSE) * (0.25f * (1.0f / 8.0f)), 1.0f / 128.0f);
-    float rcp = 1.0f / (rs_min(fabsf(d0), fabsf(d1)) + reduce);
+    const float reduce = rs_max((((lNW + lNE) + lSW) + lSE) * (0.25f * (1.0f / 8.0f)), 1.0f / 128.0f);
+    const float den = rs_min(fabsf(d0), fabsf(d1)) + reduce;
+    // Away from edges the scaled direction stays below 1 in size, every tap offset rounds to 0 and all
+    // four taps are the pixel itself: rgbA = 0.5 * (m + m) = m and rgbB = 0.5 * m + 0.25 * (m + m) = m
+    // without a rounding, so whichever the luma test picks, a channel comes out as 255 * (b / 255)
+    // truncated - and that is b again for every byte b (the product rounds to b exactly;
+    // tests/test_host.py goes through all 256).  Such a pixel passes through unchanged.
+    // |d| <= 0.99 * den keeps d * (1 / den) below 1 through the roundings of the reciprocal, of the
+    // product and of 0.99 * den.  A wave whose pixels are all like that is done here.
+    const bool calm = rs_max(fabsf(d0), fabsf(d1)) <= 0.99f * den;
+    if (rm::wave_all(calm)) {
+        *reinterpret_cast<unsigned *>(dst + (i << 2)) = centre;
+        return;
+    }
+    fx_unpack(centre, m);
+    const float lM = fx_luma(m);
+    const float lmin = rs_min(lM, rs_min(rs_min(lNW, lNE), rs_min(lSW, lSE)));
+    const float lmax = rs_max(lM, rs_max(rs_max(lNW, lNE), rs_max(lSW, lSE)));
+    const float rcp = 1.0f / den;
     d0 = rs_min(8.0f, rs_max(-8.0f, d0 * rcp));
     d1 = rs_min(8.0f, rs_max(-8.0f, d1 * rcp));
-    const float kA0 = 1.0f / 3.0f - 0.5f, kA1 = 2.0f / 2.0f - 0.5f, kB0 = 0.0f / 3.0f - 0.5f, kB1 = 3.0f / 3.0f - 0.5f;
-    size_t iA0 = (size_t)(y_inv + fx_off(d1 * kA0)) * W + (size_t)(x + fx_off(d0 * kA0));
-    size_t iA1 = (size_t)(y_inv + fx_off(d1 * kA1)) * W + (size_t)(x + fx_off(d0 * kA1));
-    size_t iB0 = (size_t)(y_inv + fx_off(d1 * kB0)) * W + (size_t)(x + fx_off(d0 * kB0));
-    size_t iB1 = (size_t)(y_inv + fx_off(d1 * kB1)) * W + (size_t)(x + fx_off(d0 * kB1));
-    float a0[3], a1[3], b0[3], b1[3], A[3], B[3];
-    fx_load(src, iA0, a0);
-    fx_load(src, iA1, a1);
-    fx_load(src, iB0, b0);
-    fx_load(src, iB1, b1);
+    // fxaa.txt:80-88: the second tap of each pair sits at the same factor, 2/2 - 1/2 = 3/3 - 1/2 = 1/2
+    // (the text's "2.0 / 2.0" where FXAA has 2/3): one fetch serves both
+    const float kA0 = 1.0f / 3.0f - 0.5f, kB0 = 0.0f / 3.0f - 0.5f, k1 = 0.5f;
+    static_assert(2.0f / 2.0f - 0.5f == 0.5f && 3.0f / 3.0f - 0.5f == 0.5f, "shared tap");
+    const unsigned iA0 = i + (unsigned)fx_off(d1 * kA0) * (unsigned)W + (unsigned)fx_off(d0 * kA0);
+    const unsigned iB0 = i + (unsigned)fx_off(d1 * kB0) * (unsigned)W + (unsigned)fx_off(d0 * kB0);
+    const unsigned i1 = i + (unsigned)fx_off(d1 * k1) * (unsigned)W + (unsigned)fx_off(d0 * k1);
+    float a0[3], t1[3], b0[3], A[3], B[3];
+    fx_unpack(in(iA0), a0);
+    fx_unpack(in(i1), t1);
+    fx_unpack(in(iB0), b0);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        A[c] = 0.5f * (a0[c] + a1[c]);
-        B[c] = A[c] * 0.5f + 0.25f * (b0[c] + b1[c]);
+        A[c] = 0.5f * (a0[c] + t1[c]);
+        B[c] = A[c] * 0.5f + 0.25f * (b0[c] + t1[c]);
     }
-    float lB = fx_luma(B);
+    const float lB = fx_luma(B);
     const bool useA = (lB < lmin) || (lB > lmax);
-    unsigned o0 = fx_u8(255.0f * (useA ? A[0] : B[0]));
-    unsigned o1 = fx_u8(255.0f * (useA ? A[1] : B[1]));
-    unsigned o2 = fx_u8(255.0f * (useA ? A[2] : B[2]));
-    *reinterpret_cast<unsigned *>(dst + i * 4) = o0 | (o1 << 8) | (o2 << 16) | (centre & 0xFF000000u);
+    const unsigned o0 = fx_u8(255.0f * (useA ? A[0] : B[0]));
+    const unsigned o1 = fx_u8(255.0f * (useA ? A[1] : B[1]));
+    const unsigned o2 = fx_u8(255.0f * (useA ? A[2] : B[2]));
+    *reinterpret_cast<unsigned *>(dst + (i << 2)) = o0 | (o1 << 8) | (o2 << 16) | (centre & 0xFF000000u);
 }
 
 // ===========================================================================
@@ -1436,6 +1456,7 @@ int rm_engine_fxaa_device(rm_engine *e, const void *d_src, void *d_dst, int row_
     if (d_src == d_dst) return fail(RM_ERR_INVALID, "FXAA runs out of place: source and destination must differ");
     if (row_begin < 0 || row_end > e->H || row_begin > row_end) return fail(RM_ERR_INVALID, "row range outside the frame");
     if (row_begin == row_end) return RM_OK;
+    if ((size_t)e->W * e->H >= ((size_t)1 << 30)) return fail(RM_ERR_UNSUPPORTED, "FXAA addresses the frame with 32-bit byte offsets: frame too large");
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_ = sync_view(e)) return rc_;
     dim3 grid((e->W + 63) / 64, (row_end - row_begin + 3) / 4);

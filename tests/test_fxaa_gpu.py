@@ -42,3 +42,40 @@ def test_fxaa_bit_exact(scene, oracle_lightmaps):
     e.synchronize()
     assert np.array_equal(dstn.cpu().numpy(), refn)
     e.close()
+
+
+@pytest.mark.parametrize("size", [(403, 301), (64, 40), (131, 9), (9, 131)])
+def test_fxaa_around_the_edge_threshold(scene, size):
+    """Images that sweep through the point where the taps leave the pixel: brightness ramps across,
+    the amplitude of a small noise ramps down the image, so scaled directions of every size near 1
+    occur at every brightness.  Odd sizes, and frames barely larger than the untouched border."""
+    import torch
+
+    import oracle
+    from raymarching_amd import Engine
+
+    W, H = size
+    rng = np.random.default_rng(W * 1000 + H)
+    ramp = np.linspace(0.0, 255.0, W)[None, :, None]
+    amp = np.linspace(0.0, 6.0, H)[:, None, None]
+    img = np.clip(np.rint(ramp + amp * rng.standard_normal((H, W, 4))), 0, 255).astype(np.uint8)
+    img[..., 3] = rng.integers(0, 256, (H, W), dtype=np.uint8)  # the fourth byte passes through
+    ref = oracle.fxaa(img)
+    e = Engine(scene, W, H)
+    src = torch.from_numpy(img).cuda()
+    dst = torch.full_like(src, 9)
+    e.fxaa_device(src.data_ptr(), dst.data_ptr(), 0, H)
+    e.synchronize()
+    got = dst.cpu().numpy()
+    assert np.array_equal(got, ref)
+    changed = (got != img).any(axis=-1).mean()
+    if W > 100 and H > 100:
+        assert 0.05 < changed < 0.95, changed  # both kinds of pixel are present
+    # a band that starts and ends inside the image
+    if H > 20:
+        dst2 = torch.full_like(src, 7)
+        e.fxaa_device(src.data_ptr(), dst2.data_ptr(), 5, H - 6)
+        e.synchronize()
+        got2 = dst2.cpu().numpy()
+        assert np.array_equal(got2[5:H - 6], ref[5:H - 6]) and (got2[:5] == 7).all() and (got2[H - 6:] == 7).all()
+    e.close()

@@ -57,14 +57,23 @@ def test_patch_range_partition(n, world):
     assert covered == list(range(n))
 
 
-def test_byte_over_255_in_three_operations():
-    """The FXAA kernel forms b/255 as q = b*c, r = fma(-q, 255, b), q + r*c with c = 1/255 in f32.
+def test_byte_over_255_in_two_operations():
+    """The FXAA kernel forms b/255 as fma(b, c, b * c_lo) with c = 1/255 in f32 and c_lo = 1/255 - c.
     For every byte this equals the correctly rounded quotient the reference's `as f32 / 255.0` gives."""
     f32 = np.float32
     c = f32(1.0) / f32(255.0)
+    c_lo = f32(1.0 / 255.0 - np.float64(c))
     for b in range(256):
         x = f32(b)
-        q = f32(x * c)
-        r = f32(np.float64(x) - np.float64(q) * 255.0)  # exact product, one rounding: a fused multiply-add
-        q2 = f32(np.float64(q) + np.float64(r) * np.float64(c))
-        assert q2 == f32(x / f32(255.0)), b
+        t = f32(x * c_lo)
+        # the product b * c is exact in float64 and so is the sum (both far inside 53 bits): one rounding, a fused multiply-add
+        q = f32(np.float64(x) * np.float64(c) + np.float64(t))
+        assert q == f32(x / f32(255.0)), b
+
+
+def test_a_byte_survives_the_round_trip_through_255():
+    """(255.0 * (b as f32 / 255.0)) as u8 == b for every byte (fxaa.txt:15-44 and :131-133): the FXAA
+    kernel relies on it to pass pixels through unchanged where all four taps fall on the pixel itself."""
+    f32 = np.float32
+    for b in range(256):
+        assert int(f32(255.0) * f32(f32(b) / f32(255.0))) == b, b
