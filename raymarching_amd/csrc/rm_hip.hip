@@ -411,44 +411,19 @@ __device__ __forceinline__ int fx_off(float o) {
 // they lie in [0, 255] and the clamp never binds
 __device__ __forceinline__ unsigned fx_u8(float f) { return (unsigned)min(max((int)f, 0), 255); }
 
-__global__ __launch_bounds__(256) void fxaa_kernel(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst,
-                                                   int W, int H, int row_begin, int row_end) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y_inv = row_begin + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y_inv >= row_end) return;
-    // byte offsets into the frame fit 32 bits (the host checks the frame size), so every tap is the
-    // base pointer plus a 32-bit offset: no 64-bit address arithmetic per fetch
+// The value of the lane below / above in the wave (all 64 lanes must be running).
+__device__ __forceinline__ float fx_from_lane_below(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float fx_from_lane_above(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
+// fxaa.txt:66-133 for a pixel whose taps may leave it: the direction, the taps, the two averages and
+// the choice between them.  `i` is the pixel's index, `centre` its four bytes.
+__device__ __forceinline__ unsigned fx_filtered(const unsigned char *__restrict__ src, unsigned i, unsigned W, unsigned centre,
+                                                float lNW, float lNE, float lSW, float lSE, float lM, float d0, float d1, float den) {
     const auto in = [src](unsigned pixel) { return *reinterpret_cast<const unsigned *>(src + (pixel << 2)); };
-    const unsigned i = (unsigned)y_inv * (unsigned)W + (unsigned)x;
-    const unsigned centre = in(i);
-    if (x < 4 || x >= W - 4 || y_inv < 4 || y_inv >= H - 4) {  // fxaa.txt:7-8 leaves the border untouched
-        *reinterpret_cast<unsigned *>(dst + (i << 2)) = centre;
-        return;
-    }
-    float nw[3], ne[3], sw[3], se[3], m[3];
-    fx_unpack(in(i - W - 1), nw);
-    fx_unpack(in(i - W + 1), ne);
-    fx_unpack(in(i + W - 1), sw);
-    fx_unpack(in(i + W + 1), se);
-    const float lNW = fx_luma(nw), lNE = fx_luma(ne), lSW = fx_luma(sw), lSE = fx_luma(se);
-    float d0 = -((lNW + lNE) - (lSW + lSE));
-    float d1 = (lNW + lSW) - (lNE + lSE);
-    const float reduce = rs_max((((lNW + lNE) + lSW) + lSE) * (0.25f * (1.0f / 8.0f)), 1.0f / 128.0f);
-    const float den = rs_min(fabsf(d0), fabsf(d1)) + reduce;
-    // Away from edges the scaled direction stays below 1 in size, every tap offset rounds to 0 and all
-    // four taps are the pixel itself: rgbA = 0.5 * (m + m) = m and rgbB = 0.5 * m + 0.25 * (m + m) = m
-    // without a rounding, so whichever the luma test picks, a channel comes out as 255 * (b / 255)
-    // truncated - and that is b again for every byte b (the product rounds to b exactly;
-    // tests/test_host.py goes through all 256).  Such a pixel passes through unchanged.
-    // |d| <= 0.99 * den keeps d * (1 / den) below 1 through the roundings of the reciprocal, of the
-    // product and of 0.99 * den.  A wave whose pixels are all like that is done here.
-    const bool calm = rs_max(fabsf(d0), fabsf(d1)) <= 0.99f * den;
-    if (rm::wave_all(calm)) {
-        *reinterpret_cast<unsigned *>(dst + (i << 2)) = centre;
-        return;
-    }
-    fx_unpack(centre, m);
-    const float lM = fx_luma(m);
     const float lmin = rs_min(lM, rs_min(rs_min(lNW, lNE), rs_min(lSW, lSE)));
     const float lmax = rs_max(lM, rs_max(rs_max(lNW, lNE), rs_max(lSW, lSE)));
     const float rcp = 1.0f / den;
@@ -458,9 +433,9 @@ __global__ __launch_bounds__(256) void fxaa_kernel(const unsigned char *__restri
     // (the text's "2.0 / 2.0" where FXAA has 2/3): one fetch serves both
     const float kA0 = 1.0f / 3.0f - 0.5f, kB0 = 0.0f / 3.0f - 0.5f, k1 = 0.5f;
     static_assert(2.0f / 2.0f - 0.5f == 0.5f && 3.0f / 3.0f - 0.5f == 0.5f, "shared tap");
-    const unsigned iA0 = i + (unsigned)fx_off(d1 * kA0) * (unsigned)W + (unsigned)fx_off(d0 * kA0);
-    const unsigned iB0 = i + (unsigned)fx_off(d1 * kB0) * (unsigned)W + (unsigned)fx_off(d0 * kB0);
-    const unsigned i1 = i + (unsigned)fx_off(d1 * k1) * (unsigned)W + (unsigned)fx_off(d0 * k1);
+    const unsigned iA0 = i + (unsigned)fx_off(d1 * kA0) * W + (unsigned)fx_off(d0 * kA0);
+    const unsigned iB0 = i + (unsigned)fx_off(d1 * kB0) * W + (unsigned)fx_off(d0 * kB0);
+    const unsigned i1 = i + (unsigned)fx_off(d1 * k1) * W + (unsigned)fx_off(d0 * k1);
     float a0[3], t1[3], b0[3], A[3], B[3];
     fx_unpack(in(iA0), a0);
     fx_unpack(in(i1), t1);
@@ -475,7 +450,70 @@ __global__ __launch_bounds__(256) void fxaa_kernel(const unsigned char *__restri
     const unsigned o0 = fx_u8(255.0f * (useA ? A[0] : B[0]));
     const unsigned o1 = fx_u8(255.0f * (useA ? A[1] : B[1]));
     const unsigned o2 = fx_u8(255.0f * (useA ? A[2] : B[2]));
-    *reinterpret_cast<unsigned *>(dst + (i << 2)) = o0 | (o1 << 8) | (o2 << 16) | (centre & 0xFF000000u);
+    return o0 | (o1 << 8) | (o2 << 16) | (centre & 0xFF000000u);
+}
+
+// A wave filters FX_COLS columns by FX_ROWS rows.  Each lane owns one column: it fetches its pixels
+// of the rows around the strip once, forms their lumas once, and takes the lumas of the columns left
+// and right of it from the neighbouring lanes - a pixel's four diagonal neighbours cost
+// (FX_ROWS + 2) / FX_ROWS fetches and lumas instead of four.  The outermost lanes only supply lumas.
+// Byte offsets into the frame fit 32 bits (the host checks the frame size), so every fetch is the
+// base pointer plus a 32-bit offset.
+#ifndef RM_FX_ROWS
+#define RM_FX_ROWS 2
+#endif
+constexpr int FX_ROWS = RM_FX_ROWS;
+constexpr int FX_COLS = 62;
+__global__ __launch_bounds__(256) void fxaa_kernel(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst,
+                                                   int W, int H, int row_begin, int row_end) {
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * FX_COLS - 1 + lane;
+    const int y0 = row_begin + (blockIdx.y * 4 + (threadIdx.x >> 6)) * FX_ROWS;
+    if (y0 >= row_end) return;  // the whole wave
+    const auto in = [src](unsigned pixel) { return *reinterpret_cast<const unsigned *>(src + (pixel << 2)); };
+    const unsigned xc = (unsigned)min(max(x, 0), W - 1);
+    unsigned px[FX_ROWS + 2];
+    float lu[FX_ROWS + 2], left[FX_ROWS + 2], right[FX_ROWS + 2];
+#pragma unroll
+    for (int r = 0; r < FX_ROWS + 2; r++) {
+        const unsigned yy = (unsigned)min(max(y0 - 1 + r, 0), H - 1);
+        px[r] = in(yy * (unsigned)W + xc);
+    }
+#pragma unroll
+    for (int r = 0; r < FX_ROWS + 2; r++) {
+        float c[3];
+        fx_unpack(px[r], c);
+        lu[r] = fx_luma(c);
+        left[r] = fx_from_lane_below(lu[r]);
+        right[r] = fx_from_lane_above(lu[r]);
+    }
+    const bool writes = lane >= 1 && lane <= FX_COLS && x < W;
+#pragma unroll
+    for (int r = 0; r < FX_ROWS; r++) {
+        const int y = y0 + r;
+        if (y >= row_end) continue;  // the whole wave
+        const unsigned i = (unsigned)y * (unsigned)W + xc;
+        const unsigned centre = px[r + 1];
+        const float lNW = left[r], lNE = right[r], lSW = left[r + 2], lSE = right[r + 2];
+        const float d0 = -((lNW + lNE) - (lSW + lSE));
+        const float d1 = (lNW + lSW) - (lNE + lSE);
+        const float reduce = rs_max((((lNW + lNE) + lSW) + lSE) * (0.25f * (1.0f / 8.0f)), 1.0f / 128.0f);
+        const float den = rs_min(fabsf(d0), fabsf(d1)) + reduce;
+        // Away from edges the scaled direction stays below 1 in size, every tap offset rounds to 0 and
+        // all four taps are the pixel itself: rgbA = 0.5 * (m + m) = m and rgbB = 0.5 * m + 0.25 * (m + m)
+        // = m without a rounding, so whichever the luma test picks, a channel comes out as
+        // 255 * (b / 255) truncated - and that is b again for every byte b (the product rounds to b
+        // exactly; tests/test_host.py goes through all 256).  Such a pixel passes through unchanged, and
+        // so does the border fxaa.txt:7-8 leaves out.  |d| <= 0.99 * den keeps d * (1 / den) below 1
+        // through the roundings of the reciprocal, of the product and of 0.99 * den.
+        const bool calm = rs_max(fabsf(d0), fabsf(d1)) <= 0.99f * den;
+        const bool filtered = writes && !calm && x >= 4 && x < W - 4 && y >= 4 && y < H - 4;
+        unsigned out = centre;
+        if (rm::wave_any(filtered)) {
+            if (filtered) out = fx_filtered(src, i, (unsigned)W, centre, lNW, lNE, lSW, lSE, lu[r + 1], d0, d1, den);
+        }
+        if (writes) *reinterpret_cast<unsigned *>(dst + (i << 2)) = out;
+    }
 }
 
 // ===========================================================================
@@ -1459,7 +1497,7 @@ int rm_engine_fxaa_device(rm_engine *e, const void *d_src, void *d_dst, int row_
     if ((size_t)e->W * e->H >= ((size_t)1 << 30)) return fail(RM_ERR_UNSUPPORTED, "FXAA addresses the frame with 32-bit byte offsets: frame too large");
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_ = sync_view(e)) return rc_;
-    dim3 grid((e->W + 63) / 64, (row_end - row_begin + 3) / 4);
+    dim3 grid((e->W + FX_COLS - 1) / FX_COLS, (row_end - row_begin + 4 * FX_ROWS - 1) / (4 * FX_ROWS));
     hipLaunchKernelGGL(fxaa_kernel, grid, dim3(256), 0, e->stream, static_cast<const unsigned char *>(d_src),
                        static_cast<unsigned char *>(d_dst), e->W, e->H, row_begin, row_end);
     HIP_TRY(hipGetLastError());
