@@ -353,23 +353,40 @@ __global__ void rad_form_kernel(const RadArgs a, int p0, int p1, int j0, const G
 constexpr int kBounceChunk = 64;  // 64 x 64 floats of FT + 64 x 3 emissive floats: 17 KiB of LDS, eight workgroups per CU
 __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0, int p1) {
     __shared__ float slab[kBounceChunk][64];
-    __shared__ float em_s[kBounceChunk][3];
+    __shared__ float em_s[kBounceChunk * 3];
+    constexpr int kPerThread = kBounceChunk / 4;  // rows of a slab each thread fetches
+    static_assert(kBounceChunk * 3 <= 256, "one emissive value per thread");
     const int NP = a.n_patches;
     const int i0 = p0 + blockIdx.x * 64;
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;  // part: row phase when loading, channel when summing
     const int i = i0 + lane;
     const bool valid = i < p1;
+    // The next slab travels from memory into registers while the current one is folded, so a fold
+    // waits for memory only once, at the first slab (with few workgroups in flight - 8 for the 512
+    // patches of the default scene - nothing else would hide that wait).
+    float pre[kPerThread], em_pre;
+    const auto fetch = [&](int j0) {
+        const int rows = min(kBounceChunk, NP - j0);
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++) {
+            const int jj = part + 4 * k;
+            pre[k] = (valid && jj < rows) ? a.ft[(size_t)(j0 + jj) * NP + i] : 0.0f;
+        }
+        em_pre = (int)threadIdx.x < rows * 3 ? a.emissive[3 * j0 + threadIdx.x] : 0.0f;
+    };
+    fetch(0);
     float acc = 0.0f;
     for (int j0 = 0; j0 < NP; j0 += kBounceChunk) {
         const int rows = min(kBounceChunk, NP - j0);
-        if (valid)
-            for (int jj = part; jj < rows; jj += 4) slab[jj][lane] = a.ft[(size_t)(j0 + jj) * NP + i];
-        for (int t = threadIdx.x; t < rows * 3; t += 256) em_s[t / 3][t % 3] = a.emissive[3 * j0 + t];
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++) slab[part + 4 * k][lane] = pre[k];
+        if (threadIdx.x < kBounceChunk * 3) em_s[threadIdx.x] = em_pre;
         __syncthreads();
+        if (j0 + kBounceChunk < NP) fetch(j0 + kBounceChunk);
         if (part < 3 && valid) {
             for (int jj = 0; jj < rows; jj++) {
                 const float f = slab[jj][lane];
-                const float term = em_s[jj][part] * f;
+                const float term = em_s[3 * jj + part] * f;
                 acc = acc + (f != -1.0f ? term : 0.0f);
             }
         }
