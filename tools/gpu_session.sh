@@ -13,6 +13,7 @@ timeout -k 10 200 python bench.py --fxaa --no-cpu-baseline > $out/bench_fxaa.jso
 timeout -k 10 200 python bench.py --width 1920 --height 1080 --fxaa --no-cpu-baseline > $out/bench_1080p_fxaa.json 2>> $out/bench.err || exit 1
 timeout -k 10 200 python bench.py --width 1920 --height 1080 --fxaa --no-cpu-baseline --frames-in-flight 2 > $out/bench_1080p_fxaa_2inflight.json 2>> $out/bench.err || exit 1
 timeout -k 10 200 python bench.py --no-cpu-baseline --frames-in-flight 2 > $out/bench_2inflight.json 2>> $out/bench.err || exit 1
+timeout -k 10 200 python bench.py --refraction --cpu-seconds 6 > $out/bench_refraction.json 2>> $out/bench.err || exit 1
 timeout -k 10 300 python bench.py --workload stress --steps 5 --warmup 1 > $out/bench_stress.json 2>> $out/bench.err || exit 1
 timeout -k 10 200 python bench.py --workload radiosity --no-cpu-baseline > $out/bench_radiosity.json 2>> $out/bench.err || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 bench.py --no-cpu-baseline > $out/trace_bench.json 2> $out/trace.log || exit 1
