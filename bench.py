@@ -186,7 +186,16 @@ def main():
     if os.environ.get("RM_BENCH_SAME_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # RM_BENCH_GATHER_ALONE=1 (rehearsal, not used by the driver): one rank forms an RCCL group by itself
+    # and runs the several-GPU path - strips, asynchronous all-gather, re-ordering, frames in flight -
+    # on the real backend; the exchange then is a copy.
+    gathering = world > 1 or os.environ.get("RM_BENCH_GATHER_ALONE") == "1"
+    if gathering and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if gathering:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -233,7 +242,7 @@ def main():
     # Sharding: without FXAA rank r renders the 8-row strips r, r+N, r+2N, ... (even load however
     # the cost is spread over the image); with FXAA it renders one contiguous band plus the few rows
     # the filter reads around it.  Either way every rank contributes the same number of rows.
-    interleaved = world > 1 and not args.fxaa
+    interleaved = gathering and not args.fxaa
     if interleaved:
         first_strip, strip_stride, strips_per_rank = strip_plan(H, rank, world)
         band_h = strips_per_rank * STRIP_ROWS
@@ -247,7 +256,7 @@ def main():
     # frames are kept in flight: measured on one GPU, an eighth of the 3840x2160 frame takes 0.132 ms
     # alone, 0.066 ms per frame with two in flight and 0.045 ms with three (0.039 would be an eighth
     # of the whole frame's time); a fourth stream gains nothing.
-    in_flight = args.frames_in_flight or (3 if world > 1 else 1)
+    in_flight = args.frames_in_flight or (3 if gathering else 1)
     if args.no_overlap:
         in_flight = 1
     n_buf = max(in_flight, 2)  # one set of buffers per frame in flight (two at least: gather f beside render f+1)
@@ -317,7 +326,7 @@ def main():
             for s in range(steps):
                 b = s & 1
                 render_band(bands[b], timed)
-                if world > 1:
+                if gathering:
                     if pending is not None:
                         finish(pending)
                     pending = (start_gather(frames[b].view(-1), bands[b].view(-1)), b)
@@ -341,7 +350,7 @@ def main():
                     finish(pending[b])
                     pending[b] = None
                 render_band(bands[b], timed)
-                if world > 1:
+                if gathering:
                     pending[b] = (start_gather(frames[b].view(-1), bands[b].view(-1)), b)
         for s in range(max(steps - in_flight, 0), steps):  # oldest frame first
             b = s % in_flight
@@ -355,7 +364,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if gathering:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -423,26 +432,26 @@ def main():
                 "ssaa": 4 if args.ssaa else 1,
                 "refraction": bool(args.refraction),
                 "map_size": 8,
-                "overlap_gather": world > 1 and not args.no_overlap,
+                "overlap_gather": gathering and not args.no_overlap,
                 "frames_in_flight": in_flight,
             },
             "roofline": roofline,
             "cap_hits": stats,
         }
-        if world > 1 and not args.fxaa:
+        if gathering and not args.fxaa:
             # the gathered frame against the same frame rendered whole on this GPU (bit for bit)
             gathered = (final if interleaved else frames)[last_buf][:H]
             local = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
             eng.render_rows_device(local.data_ptr(), 0, H)
             torch.cuda.synchronize()
             result["gathered_frame_equals_single_gpu_render"] = bool(torch.equal(gathered, local))
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N=1 only
+        if not args.no_cpu_baseline and not gathering:  # the CPU leg runs at N=1 only
             lightmaps = [eng.get_lightmap(i) for i in range(eng.n_objects)]
             base, cpu_rows = cpu_baseline(scene, lightmaps, W, H, args.cpu_seconds, args.ssaa, args.refraction)
             result["cpu_baseline"] = base
             if not args.fxaa:
                 # the same frame from the GPU: a parity check at the benchmarked size
-                full = (final if interleaved else frames)[last_buf] if world > 1 else None
+                full = (final if interleaved else frames)[last_buf] if gathering else None
                 if full is None:
                     full = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
                     eng.render_rows_device(full.data_ptr(), 0, H)
@@ -456,7 +465,7 @@ def main():
         print(json.dumps(result), flush=True)
 
     eng.close()
-    if world > 1:
+    if gathering:
         dist.barrier()
         dist.destroy_process_group()
 
