@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--refraction", action="store_true", help="the refraction block the reference carries commented out (engine.rs:196-228)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the CPU baseline leg")
+    ap.add_argument("--no-pack", action="store_true", help="exchange 4 bytes per pixel instead of 3 (the fourth byte of a pixel is always 0)")
     ap.add_argument("--no-overlap", action="store_true", help="wait for each frame's all-gather before the next render")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="1 = frames one after the other; n = consecutive frames on n streams, so that the long-running "
@@ -260,9 +261,14 @@ def main():
     if args.no_overlap:
         in_flight = 1
     n_buf = max(in_flight, 2)  # one set of buffers per frame in flight (two at least: gather f beside render f+1)
+    # Rows cross xGMI as 3 bytes per pixel (byte 3 of a rendered pixel is 0, engine.rs:116-126): a rank
+    # packs its rows before the all-gather and one kernel unpacks and orders the gathered rows.
+    packing = gathering and W % 4 == 0 and not args.no_pack
+    wire = 3 if packing else 4
     bands = [torch.zeros((band_h, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
-    frames = [torch.zeros((world * band_h, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
-    final = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if interleaved else None
+    wire_bands = [torch.zeros((band_h, W, 3), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if packing else bands
+    frames = [torch.zeros((world * band_h, W, wire), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
+    final = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if interleaved or packing else None
     fx_srcs = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if args.fxaa else None
 
     kernel_events = []
@@ -295,6 +301,8 @@ def main():
                 ev1.record(stream)
         if timed:
             kernel_events.append((ev0, ev1))
+        if packing:
+            eng.pack_bgr_device(buf.data_ptr(), wire_bands[next(i for i, b in enumerate(bands) if b is buf)].data_ptr(), band_h * W)
 
     class _HostStagedGather:
         """gloo rehearsal only: all-gather through host memory, same interface as an async work handle."""
@@ -317,7 +325,13 @@ def main():
         """Frame f is complete on this rank once its gather has landed (and, for strips, been put in row order)."""
         work, b = pending
         work.wait()
-        if interleaved:
+        if packing:
+            eng.set_stream(torch.cuda.current_stream().cuda_stream)
+            if interleaved:
+                eng.unpack_bgr_strips_device(frames[b].data_ptr(), final[b].data_ptr(), world, strips_per_rank)
+            else:  # contiguous bands are in row order already
+                eng.unpack_bgr_strips_device(frames[b].data_ptr(), final[b].data_ptr(), 1, (H + STRIP_ROWS - 1) // STRIP_ROWS)
+        elif interleaved:
             final[b].copy_(deinterleave_strips(frames[b], world, strips_per_rank, W, H))
 
     def run(steps, timed):
@@ -329,7 +343,7 @@ def main():
                 if gathering:
                     if pending is not None:
                         finish(pending)
-                    pending = (start_gather(frames[b].view(-1), bands[b].view(-1)), b)
+                    pending = (start_gather(frames[b].view(-1), wire_bands[b].view(-1)), b)
                     if args.no_overlap:
                         finish(pending)
                         pending = None
@@ -351,7 +365,7 @@ def main():
                     pending[b] = None
                 render_band(bands[b], timed)
                 if gathering:
-                    pending[b] = (start_gather(frames[b].view(-1), bands[b].view(-1)), b)
+                    pending[b] = (start_gather(frames[b].view(-1), wire_bands[b].view(-1)), b)
         for s in range(max(steps - in_flight, 0), steps):  # oldest frame first
             b = s % in_flight
             if pending[b] is not None:
@@ -433,16 +447,21 @@ def main():
                 "refraction": bool(args.refraction),
                 "map_size": 8,
                 "overlap_gather": gathering and not args.no_overlap,
+                "bytes_per_pixel_exchanged": wire if gathering else None,
                 "frames_in_flight": in_flight,
             },
             "roofline": roofline,
             "cap_hits": stats,
         }
-        if gathering and not args.fxaa:
-            # the gathered frame against the same frame rendered whole on this GPU (bit for bit)
-            gathered = (final if interleaved else frames)[last_buf][:H]
+        if gathering:
+            # the gathered frame against the same frame rendered (and filtered) whole on this GPU, bit for bit
+            gathered = (final if final is not None else frames)[last_buf][:H]
             local = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
             eng.render_rows_device(local.data_ptr(), 0, H)
+            if args.fxaa:
+                filtered = torch.zeros_like(local)
+                eng.fxaa_device(local.data_ptr(), filtered.data_ptr(), 0, H)
+                local = filtered
             torch.cuda.synchronize()
             result["gathered_frame_equals_single_gpu_render"] = bool(torch.equal(gathered, local))
         if not args.no_cpu_baseline and not gathering:  # the CPU leg runs at N=1 only
@@ -451,7 +470,7 @@ def main():
             result["cpu_baseline"] = base
             if not args.fxaa:
                 # the same frame from the GPU: a parity check at the benchmarked size
-                full = (final if interleaved else frames)[last_buf] if gathering else None
+                full = (final if final is not None else frames)[last_buf] if gathering else None
                 if full is None:
                     full = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
                     eng.render_rows_device(full.data_ptr(), 0, H)

@@ -195,6 +195,18 @@ int rm_engine_render_rows_device(rm_engine *engine, void *d_bgra, size_t pitch_b
 int rm_engine_render_strips_device(rm_engine *engine, void *d_bgra, size_t pitch_bytes, int first_strip,
                                    int strip_stride, int n_strips);
 
+/* Frames on their way between GPUs.  The fourth byte of every pixel the engine renders is 0
+ * (engine.rs:116-126; FXAA passes it through), so rows that cross xGMI travel as 3 bytes per pixel:
+ * rm_engine_pack_bgr_device turns `n_pixels` (a multiple of 4) B,G,R,0 pixels at `d_bgra` into
+ * B,G,R triples at `d_bgr`; rm_engine_unpack_bgr_strips_device rebuilds the engine's whole frame of
+ * B,G,R,0 rows at `d_bgra_frame` from the packed rows of `world` ranks as an all-gather leaves them
+ * (rank r's part holds `strips_per_rank` strips of RM_STRIP_ROWS rows: frame strips r, r+world, ...;
+ * world = 1 means the rows are already in frame order).  The frame width must be a multiple of 4.
+ * Asynchronous on the engine's stream.  No counterpart in the reference (one process). */
+int rm_engine_pack_bgr_device(rm_engine *engine, const void *d_bgra, void *d_bgr, size_t n_pixels);
+int rm_engine_unpack_bgr_strips_device(rm_engine *engine, const void *d_bgr, void *d_bgra_frame, int world,
+                                       int strips_per_rank);
+
 /* FXAA (fxaa.txt:1-135, a commented-out block nothing in the reference calls),
  * defined here out of place: every tap is read from `d_src`.  Both buffers hold
  * whole frames of width*4-byte rows; rows [row_begin,row_end) of `d_dst` are

@@ -57,6 +57,8 @@ SIGNATURES = {
     "rm_engine_render_wait": (c_int, [c_void_p]),
     "rm_engine_render_rows_device": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int]),
     "rm_engine_render_strips_device": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int]),
+    "rm_engine_pack_bgr_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "rm_engine_unpack_bgr_strips_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "rm_engine_fxaa_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "rm_engine_trace_primary": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_float)]),
     "rm_engine_probe_shade": (c_int, [c_void_p, c_int, POINTER(c_int32), POINTER(c_float), POINTER(c_float), POINTER(c_float)]),

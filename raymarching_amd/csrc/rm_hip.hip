@@ -533,6 +533,37 @@ __global__ __launch_bounds__(256) void fxaa_kernel(const unsigned char *__restri
     }
 }
 
+// ---- frames between GPUs: 3 bytes per pixel on the wire ------------------------
+
+// Four B,G,R,0 pixels (16 bytes) <-> four B,G,R triples (12 bytes).
+__global__ __launch_bounds__(256) void pack_bgr_kernel(const uint4 *__restrict__ src, unsigned *__restrict__ dst, size_t groups) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= groups) return;
+    const uint4 p = src[t];
+    dst[3 * t] = (p.x & 0xFFFFFFu) | (p.y << 24);
+    dst[3 * t + 1] = ((p.y >> 8) & 0xFFFFu) | (p.z << 16);
+    dst[3 * t + 2] = ((p.z >> 16) & 0xFFu) | (p.w << 8);
+}
+
+// Output row y of the frame comes from packed row ((s % world) * per + s / world) * 8 + y % 8 with
+// s = y / 8: strip s was rendered by rank s % world as its strip number s / world.
+__global__ __launch_bounds__(256) void unpack_bgr_strips_kernel(const unsigned *__restrict__ src, uint4 *__restrict__ dst, int W4,
+                                                                int H, int world, int per) {
+    const int g = blockIdx.x * 256 + threadIdx.x;  // group of four pixels in the row
+    const int y = blockIdx.y;
+    if (g >= W4) return;
+    const int s = y / RM_STRIP_ROWS;
+    const size_t srow = (size_t)((s % world) * per + s / world) * RM_STRIP_ROWS + (y % RM_STRIP_ROWS);
+    const unsigned *w = src + (srow * W4 + g) * 3;
+    const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
+    uint4 p;
+    p.x = w0 & 0xFFFFFFu;
+    p.y = (w0 >> 24) | ((w1 & 0xFFFFu) << 8);
+    p.z = (w1 >> 16) | ((w2 & 0xFFu) << 16);
+    p.w = w2 >> 8;
+    dst[(size_t)y * W4 + g] = p;
+}
+
 // ===========================================================================
 // Host runtime
 // ===========================================================================
@@ -1517,6 +1548,34 @@ int rm_engine_fxaa_device(rm_engine *e, const void *d_src, void *d_dst, int row_
     dim3 grid((e->W + FX_COLS - 1) / FX_COLS, (row_end - row_begin + 4 * FX_ROWS - 1) / (4 * FX_ROWS));
     hipLaunchKernelGGL(fxaa_kernel, grid, dim3(256), 0, e->stream, static_cast<const unsigned char *>(d_src),
                        static_cast<unsigned char *>(d_dst), e->W, e->H, row_begin, row_end);
+    HIP_TRY(hipGetLastError());
+    return RM_OK;
+}
+
+int rm_engine_pack_bgr_device(rm_engine *e, const void *d_bgra, void *d_bgr, size_t n_pixels) {
+    if (!e || !d_bgra || !d_bgr) return fail(RM_ERR_INVALID, "NULL argument");
+    if (n_pixels % 4) return fail(RM_ERR_INVALID, "pixels are packed four at a time: the count must be a multiple of 4");
+    if (n_pixels == 0) return RM_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t groups = n_pixels / 4;
+    if ((groups + 255) / 256 > 0x7FFFFFFFu) return fail(RM_ERR_UNSUPPORTED, "too many pixels for one launch");
+    hipLaunchKernelGGL(pack_bgr_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, e->stream,
+                       static_cast<const uint4 *>(d_bgra), static_cast<unsigned *>(d_bgr), groups);
+    HIP_TRY(hipGetLastError());
+    return RM_OK;
+}
+
+int rm_engine_unpack_bgr_strips_device(rm_engine *e, const void *d_bgr, void *d_bgra_frame, int world, int strips_per_rank) {
+    if (!e || !d_bgr || !d_bgra_frame) return fail(RM_ERR_INVALID, "NULL argument");
+    if (e->W % 4) return fail(RM_ERR_UNSUPPORTED, "packed rows need a frame width that is a multiple of 4");
+    const int strips = (e->H + RM_STRIP_ROWS - 1) / RM_STRIP_ROWS;
+    if (world < 1 || strips_per_rank < 1 || (long long)world * strips_per_rank < strips)
+        return fail(RM_ERR_INVALID, "the ranks' strips do not cover the frame");
+    if (e->H > 65535) return fail(RM_ERR_UNSUPPORTED, "frame too high for one launch");
+    HIP_TRY(hipSetDevice(e->device));
+    const int W4 = e->W / 4;
+    hipLaunchKernelGGL(unpack_bgr_strips_kernel, dim3((W4 + 255) / 256, e->H), dim3(256), 0, e->stream,
+                       static_cast<const unsigned *>(d_bgr), static_cast<uint4 *>(d_bgra_frame), W4, e->H, world, strips_per_rank);
     HIP_TRY(hipGetLastError());
     return RM_OK;
 }

@@ -187,6 +187,17 @@ class Engine:
             "rm_engine_render_strips_device",
         )
 
+    def pack_bgr_device(self, d_bgra: int, d_bgr: int, n_pixels: int):
+        """B,G,R,0 pixels -> B,G,R triples (the form rows take between GPUs); n_pixels % 4 == 0 (async)."""
+        _lib.check(self.lib.rm_engine_pack_bgr_device(self.handle, c_void_p(d_bgra), c_void_p(d_bgr), n_pixels), "rm_engine_pack_bgr_device")
+
+    def unpack_bgr_strips_device(self, d_bgr: int, d_bgra_frame: int, world: int, strips_per_rank: int):
+        """All-gathered packed strips of `world` ranks -> the whole B,G,R,0 frame in row order (async)."""
+        _lib.check(
+            self.lib.rm_engine_unpack_bgr_strips_device(self.handle, c_void_p(d_bgr), c_void_p(d_bgra_frame), world, strips_per_rank),
+            "rm_engine_unpack_bgr_strips_device",
+        )
+
     def fxaa_device(self, d_src: int, d_dst: int, row_begin: int, row_end: int):
         _lib.check(self.lib.rm_engine_fxaa_device(self.handle, c_void_p(d_src), c_void_p(d_dst), row_begin, row_end), "rm_engine_fxaa_device")
 

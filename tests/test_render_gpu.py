@@ -123,6 +123,43 @@ def test_strips_equal_full_frame(scene, gpu_engine):
         assert torch.equal(frame, full), world
 
 
+def test_packed_strips_reassemble_to_the_frame(scene, gpu_engine):
+    """Strips travel between GPUs as 3 bytes per pixel (the fourth byte of a rendered pixel is 0):
+    every rank's strips packed, laid out as an all-gather leaves them and unpacked again give the
+    full frame bit for bit, for rank counts that do and do not divide the number of strips."""
+    import torch
+
+    from raymarching_amd import dist as rdist
+
+    gpu_engine.camera_position = scene.camera_position
+    gpu_engine.input(0, 0, (0, 0, 0), 0)
+    full = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+    gpu_engine.render_rows_device(full.data_ptr(), 0, H)
+    gpu_engine.synchronize()
+    assert int(full[..., 3].max()) == 0
+    for world in (1, 2, 3, 8):
+        _, _, per = rdist.strip_plan(H, 0, world)
+        gathered = torch.full((world, per * 8, W, 3), 0xAB, dtype=torch.uint8, device="cuda")
+        for rank in range(world):
+            first, stride, per = rdist.strip_plan(H, rank, world)
+            buf = torch.zeros((per * 8, W, 4), dtype=torch.uint8, device="cuda")
+            gpu_engine.render_strips_device(buf.data_ptr(), first, stride, per)
+            gpu_engine.pack_bgr_device(buf.data_ptr(), gathered[rank].data_ptr(), per * 8 * W)
+            gpu_engine.synchronize()
+            assert torch.equal(gathered[rank], buf[..., :3]), (world, rank)
+        frame = torch.full((H, W, 4), 0xCD, dtype=torch.uint8, device="cuda")
+        gpu_engine.unpack_bgr_strips_device(gathered.data_ptr(), frame.data_ptr(), world, per)
+        gpu_engine.synchronize()
+        assert torch.equal(frame, full), world
+    # rows already in frame order (contiguous bands): world = 1
+    packed = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+    gpu_engine.pack_bgr_device(full.data_ptr(), packed.data_ptr(), H * W)
+    frame = torch.empty_like(full)
+    gpu_engine.unpack_bgr_strips_device(packed.data_ptr(), frame.data_ptr(), 1, (H + 7) // 8)
+    gpu_engine.synchronize()
+    assert torch.equal(frame, full)
+
+
 def test_probe_shade_matches_oracle(scene, gpu_engine, oracle_lightmaps):
     """Engine::shade_object at scattered surface points, including the reflective spheres."""
     lm, _ = oracle_lightmaps
