@@ -328,16 +328,26 @@ __global__ void rad_form_kernel(const RadArgs a, int p0, int p1, int j0, const G
         V3 to_light = src - sample_pos;
         float dist = mag(to_light);
         to_light = to_light / dist;
-        V3 back = -to_light;
-        V3 rp = src + back * (3.0f * SMALL_DISTANCE);  // radiosity.rs:131
-        int steps;
-        bool capped;
-        int hit = march(acc_of(grp), rp, back, -1, 0, steps, capped);
-        bool blocked = (hit >= 0) && (hit != recv_obj) && (mag_sqd(rp - sample_pos) > 0.1f * 0.1f);
-        if (!blocked) {
-            float att = dot(sample_n, to_light) * -dot(src_n, to_light);
-            float diffuse = rs_max(att, 0.0f) / (dist * dist);
-            f = rs_min(diffuse, 2.0f);
+        // radiosity.rs:147-152: what the pair contributes per unit of emission if nothing is in the way
+        const float att = dot(sample_n, to_light) * -dot(src_n, to_light);
+        const float diffuse = rs_max(att, 0.0f) / (dist * dist);
+        const float open = rs_min(diffuse, 2.0f);
+        // A pair that faces away contributes emission * 0 if it is open and nothing if it is blocked:
+        // +0 or -0 added to a sum that started at +0 leaves it as it is either way (emission values are
+        // finite), so the occlusion march is run only where its outcome can show.  A wave whose 64
+        // receivers all face away from the source skips it altogether.
+        const bool matters = !(open == 0.0f);
+        f = open;
+        if (wave_any(matters)) {
+            if (matters) {
+                V3 back = -to_light;
+                V3 rp = src + back * (3.0f * SMALL_DISTANCE);  // radiosity.rs:131
+                int steps;
+                bool capped;
+                int hit = march(acc_of(grp), rp, back, -1, 0, steps, capped);
+                bool blocked = (hit >= 0) && (hit != recv_obj) && (mag_sqd(rp - sample_pos) > 0.1f * 0.1f);
+                if (blocked) f = -1.0f;
+            }
         }
     }
     a.ft[(size_t)j * a.n_patches + i] = f;
