@@ -670,10 +670,10 @@ RM_DEV int march(const SC &sc, V3 &pos, V3 dir, int ignore, int cap, int &steps,
 
 // ray.rs:87-118, same loop shape: finished lanes are frozen by selects.
 template <class SC, class IGN>
-RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float light_dist, float k) {
+RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float light_dist, float k, LaneMask wanted) {
     float travelled = 0.0f;
     float shade = 1.0f;
-    LaneMask act = lanes_here();
+    LaneMask act = lanes_here() & wanted;
     SphereBound sb = make_bound(sc, pos, dir, light_dist);
     for (int it = 0; it < MAX_SHAD_IT; it++) {
         const bool active = lanes_in(act);
@@ -701,11 +701,15 @@ RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float lig
     return rs_clamp(shade, 0.0f, 1.0f);
 }
 
+// `wanted` = false in a lane whose caller has no use for the value (it returns 1 there): such lanes
+// do not keep the wave's loop running, and a wave without a wanted lane skips it.
 template <class SC>
-RM_DEV float smooth_shadow_march(const SC &sc, V3 pos, V3 dir, int ignore, float light_dist, float k) {
+RM_DEV float smooth_shadow_march(const SC &sc, V3 pos, V3 dir, int ignore, float light_dist, float k, bool wanted = true) {
+    const LaneMask want = __builtin_amdgcn_ballot_w64(wanted);
+    if (want == 0) return 1.0f;
     const int u = __builtin_amdgcn_readfirstlane(ignore);
-    if (wave_all(ignore == u)) return shadow_with(sc, pos, dir, UniformIgnore{u}, light_dist, k);
-    return shadow_with(sc, pos, dir, LaneIgnore{ignore}, light_dist, k);
+    if (wave_all(ignore == u)) return shadow_with(sc, pos, dir, UniformIgnore{u}, light_dist, k, want);
+    return shadow_with(sc, pos, dir, LaneIgnore{ignore}, light_dist, k, want);
 }
 
 // objects.rs:135-141 for a per-lane object.  The evaluations sit inside one dispatch on the type,
@@ -930,7 +934,11 @@ RM_DEV ShadeResult shade_local(const SC &sc, const SceneView &sv, int idx, V3 po
     float diffuse = 0.5f, specular = 0.0f;
     if (!(RM_ABL & 128)) phong_ds(n, to_light, dist, sv.intensity, sr, dir, diffuse, specular);
     diag_lap(DG_SHADE);
-    float shade = (RM_ABL & 1) ? 1.0f : smooth_shadow_march(sc, pos, to_light, idx, dist, SHADOW_K);
+    // engine.rs:194 multiplies the shade by diffuse + specular: where that is +-0 (the surface faces
+    // away from the light) the product is that zero for any shade - a finite value in [0, 1] - and the
+    // shadow ray is not cast
+    const bool lit = !(diffuse + specular == 0.0f);
+    float shade = (RM_ABL & 1) ? 1.0f : smooth_shadow_march(sc, pos, to_light, idx, dist, SHADOW_K, lit);
 
     diag_lap(DG_SHADOW);
     out.final_colour = ambient + oc * (shade * (diffuse + specular));
