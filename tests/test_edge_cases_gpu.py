@@ -148,3 +148,30 @@ def test_large_frame_leaves_in_bands(oracle_lightmaps):
     _lib.check(lib.rm_engine_render(eng.handle, padded.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), pitch, -60, 25, _lib.f3((0.0, 0.0, 0.0)), 0), "pageable, padded pitch")
     assert np.array_equal(padded[:, : w * 4].reshape(h, w, 4), ref) and (padded[:, w * 4:] == 0xCD).all()
     eng.close()
+
+
+def test_bad_arguments_are_refused_with_a_message():
+    """Every entry point answers a bad call with a status and a message instead of the reference's
+    abort: sizes and modes outside what a kernel assumes never reach a launch."""
+    import torch
+
+    from raymarching_amd import Engine, _lib, default_scene
+
+    eng = Engine(default_scene(), 66, 40)  # a width that is not a multiple of 4
+    buf = torch.zeros((40, 66, 4), dtype=torch.uint8, device="cuda")
+    out = torch.zeros_like(buf)
+    with pytest.raises(_lib.RMError, match="multiple of 4"):
+        eng.pack_bgr_device(buf.data_ptr(), out.data_ptr(), 66 * 40 - 2)
+    with pytest.raises(_lib.RMError, match="multiple of 4"):
+        eng.unpack_bgr_strips_device(buf.data_ptr(), out.data_ptr(), 1, 5)
+    with pytest.raises(_lib.RMError, match="out of place"):
+        eng.fxaa_device(buf.data_ptr(), buf.data_ptr(), 0, 40)
+    with pytest.raises(_lib.RMError, match="row range"):
+        eng.fxaa_device(buf.data_ptr(), out.data_ptr(), 0, 41)
+    with pytest.raises(_lib.RMError, match="1 or 4"):
+        eng.set_ssaa(3)
+    eng.close()
+    eng = Engine(default_scene(), 64, 40)
+    with pytest.raises(_lib.RMError, match="do not cover"):
+        eng.unpack_bgr_strips_device(buf.data_ptr(), out.data_ptr(), 2, 2)  # 4 strips for a frame of 5
+    eng.close()
