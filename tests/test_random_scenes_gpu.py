@@ -1,0 +1,24 @@
+"""GPU parity on poses and scenes drawn at random (fixed seeds): the default scene from a dozen
+camera positions, angles and zoom levels, and rooms with one to four spheres of random size, place
+and material, some with a partition wall, each with its lightmaps computed on both sides (bit for
+bit) and rendered from several poses.  The sweep itself lives in tools/random_parity.py, which runs
+it at any length."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_poses_and_scenes(seed):
+    import random_parity
+
+    frames, worst, inexact = random_parity.run(n_poses=12, n_scenes=5, seed=seed, verbose=False)
+    print(f"seed {seed}: {frames} frames, worst max|d| = {worst}, worst inexact fraction = {inexact:.2e}")
+    # the tolerance of tests/conftest.py: 2/255 per channel, 99.9 % of the pixels exact
+    assert frames == 12 + 5 * 4
+    assert worst <= 2 and inexact <= 1e-3
