@@ -1,5 +1,5 @@
 """Random-pose and random-scene parity sweep against the oracle (run on the GPU box):
-python tools/random_parity.py [poses] [scenes]"""
+python tools/random_parity.py [poses] [scenes]   (RM_REFRACTION=1: with the refraction switch on)"""
 import os
 import sys
 
@@ -24,6 +24,9 @@ def run(n_poses=40, n_scenes=12, seed=2024, verbose=True):
     def check(scene, poses, bounces, tag):
         eng = Engine(scene, W, H)
         ora = make_oracle(scene)
+        if os.environ.get("RM_REFRACTION") == "1":  # the same sweep with the refraction switch on
+            eng.set_refraction(True)
+            ora.set_refraction(True)
         eng.compute_lightmaps(bounces)
         ora.compute_lightmaps(bounces)
         for i in range(eng.n_objects):
