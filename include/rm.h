@@ -223,6 +223,15 @@ int rm_engine_trace_primary(rm_engine *engine, int32_t *hit, int32_t *steps, flo
 int rm_engine_probe_shade(rm_engine *engine, int n, const int32_t *object, const float *position,
                           const float *direction, float *colour);
 
+/* The last pass of Engine::render for `n` arbitrary linear colours (host arrays, [n][3] in, [n] out):
+ * colour * exposure -> ACESFilm -> sqrt -> to_pixel_range -> B | G << 8 | R << 16 (engine.rs:109-125,
+ * colour.rs:33-44).  `packed` comes from the code the frames use, which estimates each channel with
+ * the hardware's one-ulp reciprocal and square root and falls back to the exact operations when an
+ * estimate lies within 2e-4 of a rounding boundary; `packed_exact` from the exact operations alone.
+ * The two must agree everywhere; a test aid with no counterpart in the reference. */
+int rm_engine_probe_pack(rm_engine *engine, int n, const float *linear, float exposure, uint32_t *packed,
+                         uint32_t *packed_exact);
+
 /* Supersampling, engine.rs:95-108 (commented out in the reference): samples = 4 casts four rays per
  * pixel - the pixel's direction moved by (+-0.5/WIDTH, 0, 0) and (0, +-0.5/HEIGHT, 0) before it is
  * normalised - and averages their linear colours ((c0 + c1) + c2 + c3) / 4 ahead of tone mapping.

@@ -1370,6 +1370,13 @@ void orc_kat_aces(const float *in, float *out) {
     for (int i = 0; i < 3; i++) out[i] = c.l[i];
 }
 int orc_kat_to_pixel_range(float v) { return to_pixel_range(v); }
+// engine.rs:110 and :120-125 for n linear colours at exposure 1: B | G << 8 | R << 16
+void orc_kat_pack_pixels(int n, const float *linear, uint32_t *out) {
+    for (int i = 0; i < n; i++) {
+        Colour s = aces_film(Colour(linear[3 * i], linear[3 * i + 1], linear[3 * i + 2]) * 1.0f).sqrt();
+        out[i] = (uint32_t)to_pixel_range(s.z()) | ((uint32_t)to_pixel_range(s.y()) << 8) | ((uint32_t)to_pixel_range(s.x()) << 16);
+    }
+}
 void orc_kat_texture_sample(void *h, int tex, float u, float v, float *out) {
     Colour c = static_cast<Engine *>(h)->textures[tex]->sample(u, v);
     for (int i = 0; i < 3; i++) out[i] = c.l[i];

@@ -4,7 +4,7 @@ There is no fallback: if the HIP library is missing, loading raises.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint64, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librm_hip.so")
@@ -62,6 +62,7 @@ SIGNATURES = {
     "rm_engine_fxaa_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "rm_engine_trace_primary": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_float)]),
     "rm_engine_probe_shade": (c_int, [c_void_p, c_int, POINTER(c_int32), POINTER(c_float), POINTER(c_float), POINTER(c_float)]),
+    "rm_engine_probe_pack": (c_int, [c_void_p, c_int, POINTER(c_float), c_float, POINTER(c_uint32), POINTER(c_uint32)]),
     "rm_engine_set_ssaa": (c_int, [c_void_p, c_int]),
     "rm_engine_set_tetrahedral_normals": (c_int, [c_void_p, c_int]),
     "rm_engine_set_refraction": (c_int, [c_void_p, c_int]),

@@ -1129,11 +1129,31 @@ RM_DEV unsigned to_pixel_range(float i) {
 }
 
 // engine.rs:109-125 for one pixel: linear colour -> packed B,G,R,0 bytes
+RM_DEV unsigned pack_pixel_exact(V3 c) {
+    float r = sqrt_rn(aces(c.x)), g = sqrt_rn(aces(c.y)), b = sqrt_rn(aces(c.z));
+    return to_pixel_range(b) | (to_pixel_range(g) << 8) | (to_pixel_range(r) << 16);
+}
+
+// One channel of the same through the hardware's one-ulp reciprocal and square root: y estimates
+// 255 * sqrt(ACES(x)) to within 7e-5 (three roundings and two one-ulp functions on a value of at most
+// 260), and so does the value the exact operations produce.  Where y is a finite non-negative number
+// at least 2e-4 away from every k + 1/2, both round to the same byte; `sure` says so.
+RM_DEV unsigned channel_estimate(float x, bool &sure) {
+    const float num = x * (2.51f * x + 0.03f), den = x * (2.43f * x + 0.59f) + 0.14f;
+    const float y = 255.0f * __builtin_amdgcn_sqrtf(num * __builtin_amdgcn_rcpf(den));
+    const float fl = floorf(y), fr = y - fl;
+    sure = sure && y >= 0.0f && y < 1e6f && fabsf(fr - 0.5f) > 2e-4f;
+    const float rounded = fl + (fr > 0.5f ? 1.0f : 0.0f);
+    return (unsigned)fminf(rounded, 255.0f);
+}
+
 RM_DEV unsigned pack_pixel(V3 linear, float exposure) {
     V3 c = linear * exposure;
     if (RM_ABL & 16) return to_pixel_range(c.x) | (to_pixel_range(c.y) << 8) | (to_pixel_range(c.z) << 16);
-    float r = sqrt_rn(aces(c.x)), g = sqrt_rn(aces(c.y)), b = sqrt_rn(aces(c.z));
-    return to_pixel_range(b) | (to_pixel_range(g) << 8) | (to_pixel_range(r) << 16);
+    bool sure = true;
+    const unsigned r = channel_estimate(c.x, sure), g = channel_estimate(c.y, sure), b = channel_estimate(c.z, sure);
+    if (wave_all(sure)) return b | (g << 8) | (r << 16);
+    return pack_pixel_exact(c);  // a lane close to a rounding boundary, or not a number: the whole wave takes the exact operations
 }
 
 }  // namespace rm

@@ -242,6 +242,16 @@ __global__ void probe_shade_kernel(const SceneView *svp, int n, const int *obj, 
     body(acc_of(g));
 }
 
+// Tone map and pack (engine.rs:109-125) for arbitrary linear colours: the path the frames take
+// (estimate, exact operations only near a rounding boundary) and the exact operations alone.
+__global__ void probe_pack_kernel(int n, const float *linear, float exposure, unsigned *packed, unsigned *packed_exact) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 c = v3(linear[3 * i], linear[3 * i + 1], linear[3 * i + 2]);
+    packed[i] = pack_pixel(c, exposure);
+    packed_exact[i] = pack_pixel_exact(c * exposure);
+}
+
 // ---- radiosity -------------------------------------------------------------
 
 struct RadArgs {
@@ -1645,6 +1655,29 @@ int rm_engine_probe_shade(rm_engine *e, int n, const int32_t *object, const floa
     (void)hipFree(d_dir);
     (void)hipFree(d_out);
     if (err != hipSuccess) return fail(RM_ERR_HIP, std::string("probe_shade: ") + hipGetErrorString(err));
+    return RM_OK;
+}
+
+int rm_engine_probe_pack(rm_engine *e, int n, const float *linear, float exposure, uint32_t *packed, uint32_t *packed_exact) {
+    if (!e || !linear || !packed || !packed_exact || n < 0) return fail(RM_ERR_INVALID, "bad argument");
+    if (n == 0) return RM_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    float *d_in = nullptr;
+    unsigned *d_out = nullptr;
+    hipError_t err = dev_alloc(&d_in, (size_t)n * 3);
+    if (err == hipSuccess) err = dev_alloc(&d_out, (size_t)n * 2);
+    if (err == hipSuccess) err = hipMemcpy(d_in, linear, sizeof(float) * 3 * n, hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(probe_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, (const float *)d_in, exposure, d_out,
+                           d_out + n);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (err == hipSuccess) err = hipMemcpy(packed, d_out, sizeof(unsigned) * n, hipMemcpyDeviceToHost);
+    if (err == hipSuccess) err = hipMemcpy(packed_exact, d_out + n, sizeof(unsigned) * n, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (err != hipSuccess) return fail(RM_ERR_HIP, std::string("probe_pack: ") + hipGetErrorString(err));
     return RM_OK;
 }
 

@@ -225,6 +225,20 @@ class Engine:
         )
         return out
 
+    def probe_pack(self, linear, exposure=1.0):
+        """Tone map and pack [n][3] linear colours: (as the frames do it, by the exact operations alone)."""
+        from ctypes import c_uint32
+
+        linear = np.ascontiguousarray(linear, dtype=np.float32).reshape(-1, 3)
+        fast = np.empty(len(linear), dtype=np.uint32)
+        exact = np.empty(len(linear), dtype=np.uint32)
+        _lib.check(
+            self.lib.rm_engine_probe_pack(self.handle, len(linear), linear.ctypes.data_as(POINTER(c_float)), float(exposure),
+                                          fast.ctypes.data_as(POINTER(c_uint32)), exact.ctypes.data_as(POINTER(c_uint32))),
+            "rm_engine_probe_pack",
+        )
+        return fast, exact
+
     def set_ssaa(self, samples):
         """engine.rs:95-108: 4 = four rays per pixel, averaged; 1 = off."""
         _lib.check(self.lib.rm_engine_set_ssaa(self.handle, samples), "rm_engine_set_ssaa")

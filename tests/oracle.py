@@ -74,6 +74,7 @@ def load(counting=False):
     lib.orc_kat_rgb.argtypes = [c_float, c_float, c_float, _F]
     lib.orc_kat_aces.argtypes = [_F, _F]
     lib.orc_kat_to_pixel_range.argtypes = [c_float]
+    lib.orc_kat_pack_pixels.argtypes = [c_int, _F, POINTER(ctypes.c_uint32)]
     lib.orc_kat_texture_sample.argtypes = [c_void_p, c_int, c_float, c_float, _F]
     lib.orc_kat_sdf.restype = c_float
     lib.orc_kat_sdf.argtypes = [c_void_p, c_int, _F]

@@ -350,3 +350,43 @@ def test_frame_sequence_with_recorded_input(scene, oracle_lightmaps):
     for b in bufs:
         lib.rm_host_free(b)
     eng.close()
+
+
+def test_tone_map_estimate_never_disagrees_with_the_exact_operations(gpu_engine):
+    """engine.rs:109-125: the frames pack a pixel from one-ulp estimates of the division and the
+    square root and take the exact operations only near a rounding boundary.  Both paths side by side
+    on 12 million colours: random ones over the whole range, every float around the 255 boundaries of
+    each byte (found by bisection on the exact path), zeros, negatives, infinities and NaNs - and the
+    exact path against the oracle's restatement on a sample."""
+    import ctypes
+
+    import oracle as orc
+
+    rng = np.random.default_rng(42)
+    parts = [rng.uniform(0.0, 1.2, (4_000_000, 3)), 10.0 ** rng.uniform(-12, 3, (2_000_000, 3)),
+             np.array([[0.0, -0.0, 1.0], [np.inf, -np.inf, np.nan], [-1.0, -1e-30, 1e-45], [3e38, 1e30, 1e-38]])]
+    # the inputs where the exact byte changes: bisect x for each boundary k - 1/2 -> k, then take a
+    # window of neighbouring floats on both sides
+    lo = np.zeros(255, dtype=np.float32)
+    hi = np.full(255, 64.0, dtype=np.float32)
+    target = np.arange(1, 256, dtype=np.uint32)
+    for _ in range(40):
+        mid = ((lo.astype(np.float64) + hi.astype(np.float64)) / 2).astype(np.float32)
+        _, exact = gpu_engine.probe_pack(np.stack([mid, mid, mid], axis=1))
+        below = (exact & 255) < target
+        lo = np.where(below, mid, lo)
+        hi = np.where(below, hi, mid)
+    window = np.arange(-4000, 4001, dtype=np.int64)
+    near = (hi.view(np.uint32).astype(np.int64)[:, None] + window[None, :]).astype(np.uint32).view(np.float32).reshape(-1)
+    parts.append(np.stack([near, near[::-1], np.roll(near, 12345)], axis=1))
+    colours = np.concatenate(parts).astype(np.float32)
+    fast, exact = gpu_engine.probe_pack(colours)
+    assert np.array_equal(fast, exact), np.flatnonzero(fast != exact)[:10]
+    assert len(np.unique(exact[-len(near):] & 255)) == 256  # the window really crosses every boundary
+    # the exact path is the oracle's arithmetic (colour.rs:33-44, engine.rs:21-22, 110)
+    lib = orc.load()
+    sample = colours[rng.integers(0, len(colours), 20000)]
+    want = np.empty(len(sample), dtype=np.uint32)
+    lib.orc_kat_pack_pixels(len(sample), sample.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), want.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+    _, got = gpu_engine.probe_pack(sample)
+    assert np.array_equal(got, want)
