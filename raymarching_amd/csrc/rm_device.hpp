@@ -621,8 +621,12 @@ RM_DEV int march_capped(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, 
 // The same loop for the usual case of no iteration cap, written so that the wave
 // runs it with one scalar back-edge: lanes that have finished are frozen by
 // selects instead of being peeled off through execution-mask bookkeeping.
+// `first` (the same in every lane) is the loop's first distance evaluation where the caller has
+// made it already: the distance from `pos` to the nearest object, at least SMALL_DISTANCE and below
+// MAX_MARCH_DISTANCE, and `first_sph` the distance to the nearest sphere.  NaN = not known.
 template <class SC, class IGN>
-RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, int &steps, bool &capped) {
+RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, int &steps, bool &capped, float first,
+                      float first_sph) {
     if (cap > 0) return march_capped(sc, pos, dir, ign, cap, steps, capped);
     capped = false;
     steps = 0;
@@ -630,6 +634,13 @@ RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, in
     LaneMask act = lanes_here();  // travelled = 0 < MAX_MARCH_DISTANCE
     LaneMask hit_lanes = 0;
     SphereBound sb = make_bound(sc, pos, dir, MAX_MARCH_DISTANCE);
+    if (first == first) {
+        // the first turn of the loop below with its distance given: no hit, the step taken
+        steps = 1;
+        travelled = first;
+        pos = pos + dir * first;
+        sb.T = first_sph - sb.M;  // the carried bound as the evaluation at travelled = 0 would have left it
+    }
     do {
         const bool active = lanes_in(act);
         diag_iter(active, 1);
@@ -659,13 +670,14 @@ RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, in
 // (the usual case: neighbouring pixels hit the same surface) takes the variant
 // that drops it by a scalar branch.
 template <class SC>
-RM_DEV int march(const SC &sc, V3 &pos, V3 dir, int ignore, int cap, int &steps, bool &capped) {
+RM_DEV int march(const SC &sc, V3 &pos, V3 dir, int ignore, int cap, int &steps, bool &capped,
+                 float first = __builtin_nanf(""), float first_sph = __builtin_nanf("")) {
     const int u = __builtin_amdgcn_readfirstlane(ignore);
     if (wave_all(ignore == u)) {
-        if (u < 0) return march_with(sc, pos, dir, NoIgnore{}, cap, steps, capped);
-        return march_with(sc, pos, dir, UniformIgnore{u}, cap, steps, capped);
+        if (u < 0) return march_with(sc, pos, dir, NoIgnore{}, cap, steps, capped, first, first_sph);
+        return march_with(sc, pos, dir, UniformIgnore{u}, cap, steps, capped, __builtin_nanf(""), 0.0f);
     }
-    return march_with(sc, pos, dir, LaneIgnore{ignore}, cap, steps, capped);
+    return march_with(sc, pos, dir, LaneIgnore{ignore}, cap, steps, capped, __builtin_nanf(""), 0.0f);
 }
 
 // ray.rs:87-118, same loop shape: finished lanes are frozen by selects.
@@ -951,7 +963,8 @@ RM_DEV ShadeResult shade_local(const SC &sc, const SceneView &sv, int idx, V3 po
 // engine.rs:129-145 + 231-241 with the recursion turned into an explicit stack;
 // frames unwind innermost first, which keeps every rounding of the recursion.
 template <class SC>
-RM_DEV V3 cast_sight_ray(const SC &sc, const SceneView &sv, V3 pos, V3 dir) {
+RM_DEV V3 cast_sight_ray(const SC &sc, const SceneView &sv, V3 pos, V3 dir, float first = __builtin_nanf(""),
+                         float first_sph = __builtin_nanf("")) {
     float stk[MAX_DEPTH][7];
     int depth = 0;
     V3 colour;
@@ -960,7 +973,8 @@ RM_DEV V3 cast_sight_ray(const SC &sc, const SceneView &sv, V3 pos, V3 dir) {
         bool capped;
         diag_lap(DG_REFLECT);
         diag_event(5);
-        int idx = march(sc, pos, dir, -1, sv.march_cap, steps, capped);
+        int idx = march(sc, pos, dir, -1, sv.march_cap, steps, capped, first, first_sph);
+        first = __builtin_nanf("");  // known for the ray from the camera only
         if (capped) atomicAdd(&sv.stats[1], 1ULL);
         if (idx < 0) {
             colour = v3(sv.sky[0], sv.sky[1], sv.sky[2]);

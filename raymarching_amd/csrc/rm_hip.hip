@@ -42,6 +42,12 @@ struct RenderArgs {
     int tile_row_stride;  // 1 = contiguous rows; n = every n-th 8-row strip, written compactly
     unsigned char *out;  // first byte of row `row_begin`
     size_t pitch;
+    // Every primary ray starts at the camera, so the first distance evaluation of every primary march
+    // is the same: the host makes it once per frame.  camera_dist = distance from the camera to the
+    // nearest object, camera_sph = to the nearest sphere (+inf without spheres); camera_dist is NaN
+    // where that does not apply (scene tiers with a spatial index or smooth unions; a camera closer
+    // than SMALL_DISTANCE to something, farther than MAX_MARCH_DISTANCE from everything, or not a number).
+    float camera_dist, camera_sph;
 };
 
 // Workgroup -> tile.  Tiles are handed out bottom row first: in scenes with a
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderArgs 
     V3 dir = pixel_direction(a.pose, x, y_inv);
     V3 cam = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
     diag_lap(DG_SETUP);
-    V3 colour = cast_sight_ray(acc_of(g), *a.sv, cam, dir);
+    V3 colour = cast_sight_ray(acc_of(g), *a.sv, cam, dir, a.camera_dist, a.camera_sph);
     diag_lap(DG_REFLECT);
 #ifdef RM_DIAG
     __syncthreads();
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_kernel(const RenderArgs a
     V3 pos = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
     int steps;
     bool capped;
-    int idx = march(acc_of(g), pos, dir, -1, a.sv->march_cap, steps, capped);
+    int idx = march(acc_of(g), pos, dir, -1, a.sv->march_cap, steps, capped, a.camera_dist, a.camera_sph);
     size_t i = (size_t)y_inv * a.pose.W + x;
     if (hit) hit[i] = idx;
     if (steps_out) steps_out[i] = steps;
@@ -1183,6 +1189,35 @@ static int sync_view(rm_engine *e) {
     return RM_OK;
 }
 
+// The first distance evaluation of every primary march, in the operations of the march loop
+// (objects.rs:261,275,295,315,334): see RenderArgs.
+static void camera_distances(const rm_engine *e, float &nearest, float &nearest_sphere) {
+    nearest = NAN;
+    nearest_sphere = INFINITY;
+    if (e->tier > 1 || e->scene.smooth_k > 0.0f) return;  // the by-value scene tiers only
+    const float *p = e->pose.cam;
+    float d = INFINITY;
+    for (const HostObject &o : e->scene.objects) {
+        float s;
+        switch (o.type) {
+            case T_SPHERE: {
+                const float x = p[0] - o.p[0], y = p[1] - o.p[1], z = p[2] - o.p[2];
+                s = sqrtf((x * x + y * y) + z * z) - o.p[3];
+                nearest_sphere = fminf(nearest_sphere, s);
+                break;
+            }
+            case T_XPLANE: s = o.p[1] * (p[0] - o.p[0]); break;
+            case T_YPLANE: s = o.p[1] * (p[1] - o.p[0]); break;
+            case T_ZPLANE: s = o.p[1] * (p[2] - o.p[0]); break;
+            case T_PLANE: s = ((p[0] * o.p[0] + p[1] * o.p[1]) + p[2] * o.p[2]) - o.p[3]; break;
+            default: return;  // boxes live in the large tier
+        }
+        if (!(s == s)) return;
+        d = fminf(d, s);
+    }
+    if (d >= SMALL_DISTANCE && d < MAX_MARCH_DISTANCE) nearest = d;
+}
+
 static RenderArgs make_render_args(rm_engine *e, void *d_out, size_t pitch, int row_begin, int row_end, dim3 &grid) {
     RenderArgs a;
     a.sv = e->d_view;
@@ -1194,6 +1229,7 @@ static RenderArgs make_render_args(rm_engine *e, void *d_out, size_t pitch, int 
     a.tile_row_stride = 1;
     a.out = static_cast<unsigned char *>(d_out);
     a.pitch = pitch;
+    camera_distances(e, a.camera_dist, a.camera_sph);
     grid = dim3((unsigned)(a.blocks_x * a.blocks_y), 1, 1);
     return a;
 }
