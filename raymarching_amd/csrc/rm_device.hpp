@@ -1037,7 +1037,8 @@ RM_DEV V3 internal_march(int type, const Geom &g, V3 pos, V3 dir) {
 // starts at shade_object for that object at `pos` instead of marching (engine.rs:147).
 constexpr float REFRACTION_IOR = 2.5f;
 template <class SC>
-RM_DEV V3 cast_sight_tree(const SC &sc, const SceneView &sv, V3 pos, V3 dir, int first_hit = -1) {
+RM_DEV V3 cast_sight_tree(const SC &sc, const SceneView &sv, V3 pos, V3 dir, int first_hit = -1,
+                          float first = __builtin_nanf(""), float first_sph = __builtin_nanf("")) {
     struct Frame {
         V3 acc, oc;       // the hit's colour so far (engine.rs:194, then :225 added); its object colour
         V3 rpos, rdir;    // the mirror ray, cast once the refracted subtree is done (engine.rs:235-237)
@@ -1053,10 +1054,11 @@ RM_DEV V3 cast_sight_tree(const SC &sc, const SceneView &sv, V3 pos, V3 dir, int
         if (idx < 0) {
             int steps;
             bool capped;
-            idx = march(sc, pos, dir, ignore, sv.march_cap, steps, capped);
+            idx = march(sc, pos, dir, ignore, sv.march_cap, steps, capped, first, first_sph);
             if (capped) atomicAdd(&sv.stats[1], 1ULL);
         }
         first_hit = -1;
+        first = __builtin_nanf("");  // known for the ray from the camera only
         bool have = true;
         V3 val = v3(sv.sky[0], sv.sky[1], sv.sky[2]);
         if (idx < 0) {

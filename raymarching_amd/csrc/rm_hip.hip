@@ -160,7 +160,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_ssaa_kernel(const Render
     V3 sum = v3(0.0f, 0.0f, 0.0f);
     for (int i = 0; i < 4; i++) {
         const V3 off = i == 0 ? v3(ox, 0.0f, 0.0f) : i == 1 ? v3(-ox, 0.0f, 0.0f) : i == 2 ? v3(0.0f, oy, 0.0f) : v3(0.0f, -oy, 0.0f);
-        const V3 c = cast_sight_ray(acc_of(g), *a.sv, cam, normalized(dir + off));
+        const V3 c = cast_sight_ray(acc_of(g), *a.sv, cam, normalized(dir + off), a.camera_dist, a.camera_sph);
         sum = i == 0 ? c : sum + c;
     }
     unsigned px = pack_pixel(sum / 4.0f, a.pose.exposure);
@@ -183,12 +183,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_tree_kernel(const Render
         V3 sum = v3(0.0f, 0.0f, 0.0f);
         for (int i = 0; i < 4; i++) {
             const V3 off = i == 0 ? v3(ox, 0.0f, 0.0f) : i == 1 ? v3(-ox, 0.0f, 0.0f) : i == 2 ? v3(0.0f, oy, 0.0f) : v3(0.0f, -oy, 0.0f);
-            const V3 c = cast_sight_tree(acc_of(g), *a.sv, cam, normalized(dir + off));
+            const V3 c = cast_sight_tree(acc_of(g), *a.sv, cam, normalized(dir + off), -1, a.camera_dist, a.camera_sph);
             sum = i == 0 ? c : sum + c;
         }
         colour = sum / 4.0f;
     } else {
-        colour = cast_sight_tree(acc_of(g), *a.sv, cam, dir);
+        colour = cast_sight_tree(acc_of(g), *a.sv, cam, dir, -1, a.camera_dist, a.camera_sph);
     }
     *reinterpret_cast<unsigned *>(a.out + (size_t)out_row * a.pitch + (size_t)x * 4) = pack_pixel(colour, a.pose.exposure);
 }
