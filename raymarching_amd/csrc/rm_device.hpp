@@ -628,6 +628,11 @@ template <class SC, class IGN>
 RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, int &steps, bool &capped, float first,
                       float first_sph) {
     if (cap > 0) return march_capped(sc, pos, dir, ign, cap, steps, capped);
+    // The loop below freezes a stopped lane by steps of dir * 0, which needs a finite direction; a
+    // wave holding a direction that is not (a normal taken where the surface has no gradient left)
+    // takes the plain loop.
+    if (!wave_all(fabsf(dir.x) + fabsf(dir.y) + fabsf(dir.z) < __builtin_inff()))
+        return march_capped(sc, pos, dir, ign, 0x7fffffff, steps, capped);
     capped = false;
     steps = 0;
     float travelled = 0.0f;
@@ -651,11 +656,11 @@ RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, in
         const bool go = lanes_in(go_lanes);
         steps += active ? 1 : 0;
         const float t2 = travelled + d;
-        const V3 p2 = pos + dir * d;
         travelled = t2;  // (read by running lanes only)
-        pos.x = go ? p2.x : pos.x;
-        pos.y = go ? p2.y : pos.y;
-        pos.z = go ? p2.z : pos.z;
+        // a lane that has stopped takes a step of length 0: dir * 0 is a zero with the sign of dir,
+        // which leaves every coordinate as it is (a coordinate of -0 can only have come from a
+        // direction component of -0, whose zero step is -0 as well)
+        pos = pos + dir * (go ? d : 0.0f);
         act = go_lanes & lanes_lt(t2, MAX_MARCH_DISTANCE);
     } while (act != 0);
     const bool hit = lanes_in(hit_lanes);
