@@ -702,7 +702,9 @@ RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float lig
         // is.  Lanes in that case skip the division and the polynomial.
         const float a = k * d;
         float sh2 = shade;
-        if (!(a >= travelled && travelled >= 0.0f) && active) {
+        // (travelled is a sum of earlier steps, each at least SMALL_DISTANCE, or the lane would have
+        // stopped: it is never negative in a running lane)
+        if (!(a >= travelled) && active) {
             diag_event(4);
             const float x = rs_clamp(a / travelled, 0.0f, 1.0f);
             const float ss = 3.0f * (x * x) - 2.0f * (x * (x * x));
