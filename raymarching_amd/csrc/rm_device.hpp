@@ -627,12 +627,11 @@ RM_DEV int march_capped(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, 
 template <class SC, class IGN>
 RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, int &steps, bool &capped, float first,
                       float first_sph) {
-    if (cap > 0) return march_capped(sc, pos, dir, ign, cap, steps, capped);
     // The loop below freezes a stopped lane by steps of dir * 0, which needs a finite direction; a
     // wave holding a direction that is not (a normal taken where the surface has no gradient left)
-    // takes the plain loop.
-    if (!wave_all(fabsf(dir.x) + fabsf(dir.y) + fabsf(dir.z) < __builtin_inff()))
-        return march_capped(sc, pos, dir, ign, 0x7fffffff, steps, capped);
+    // takes the plain loop, as does a march with an iteration cap.
+    if (cap > 0 || !wave_all(fabsf(dir.x) + fabsf(dir.y) + fabsf(dir.z) < __builtin_inff()))
+        return march_capped(sc, pos, dir, ign, cap > 0 ? cap : 0x7fffffff, steps, capped);
     capped = false;
     steps = 0;
     float travelled = 0.0f;
