@@ -539,10 +539,10 @@ RM_DEV int closest_index(const SC &sc, V3 p, float, const IGN &ign, bool spheres
     int bi = 0x7fffffff;
     auto take = [&](int oi, float s0) {
         const float s = ign.mask(oi, s0);
-        if (s < best || (s == best && oi < bi)) {
-            best = s;
-            bi = oi;
-        }
+        // (selects instead of a branch: bitwise operators keep the compiler from short-circuiting)
+        const bool better = (s < best) | ((s == best) & (oi < bi));
+        best = better ? s : best;
+        bi = better ? oi : bi;
     };
     sc.template axis<0>([&](int oi, float off, float dir) {
         if (!ign.skip(oi)) take(oi, dir * (p.x - off));
