@@ -1643,13 +1643,15 @@ int rm_engine_trace_primary(rm_engine *e, int32_t *hit, int32_t *steps, float *p
     size_t npx = (size_t)e->W * e->H;
     int *d_hit = nullptr, *d_steps = nullptr;
     float *d_pos = nullptr;
-    HIP_TRY(dev_alloc(&d_hit, npx));
-    HIP_TRY(dev_alloc(&d_steps, npx));
-    HIP_TRY(dev_alloc(&d_pos, npx * 3));
-    dim3 grid;
-    RenderArgs a = make_render_args(e, d_hit, (size_t)e->W * 4, 0, e->H, grid);
-    RM_LAUNCH(trace_kernel, e, grid, dim3(BLOCK_THREADS), a, d_hit, d_steps, d_pos);
-    hipError_t err = hipGetLastError();
+    hipError_t err = dev_alloc(&d_hit, npx);  // (every path below reaches the frees)
+    if (err == hipSuccess) err = dev_alloc(&d_steps, npx);
+    if (err == hipSuccess) err = dev_alloc(&d_pos, npx * 3);
+    if (err == hipSuccess) {
+        dim3 grid;
+        RenderArgs a = make_render_args(e, d_hit, (size_t)e->W * 4, 0, e->H, grid);
+        RM_LAUNCH(trace_kernel, e, grid, dim3(BLOCK_THREADS), a, d_hit, d_steps, d_pos);
+        err = hipGetLastError();
+    }
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
     if (err == hipSuccess && hit) err = hipMemcpy(hit, d_hit, npx * sizeof(int), hipMemcpyDeviceToHost);
     if (err == hipSuccess && steps) err = hipMemcpy(steps, d_steps, npx * sizeof(int), hipMemcpyDeviceToHost);
@@ -1671,11 +1673,11 @@ int rm_engine_probe_shade(rm_engine *e, int n, const int32_t *object, const floa
     if (int rc_ = sync_view(e)) return rc_;
     int *d_obj = nullptr;
     float *d_pos = nullptr, *d_dir = nullptr, *d_out = nullptr;
-    HIP_TRY(dev_alloc(&d_obj, n));
-    HIP_TRY(dev_alloc(&d_pos, (size_t)n * 3));
-    HIP_TRY(dev_alloc(&d_dir, (size_t)n * 3));
-    HIP_TRY(dev_alloc(&d_out, (size_t)n * 3));
-    hipError_t err = hipMemcpy(d_obj, object, sizeof(int) * n, hipMemcpyHostToDevice);
+    hipError_t err = dev_alloc(&d_obj, n);  // (every path below reaches the frees)
+    if (err == hipSuccess) err = dev_alloc(&d_pos, (size_t)n * 3);
+    if (err == hipSuccess) err = dev_alloc(&d_dir, (size_t)n * 3);
+    if (err == hipSuccess) err = dev_alloc(&d_out, (size_t)n * 3);
+    if (err == hipSuccess) err = hipMemcpy(d_obj, object, sizeof(int) * n, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(d_pos, position, sizeof(float) * 3 * n, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(d_dir, direction, sizeof(float) * 3 * n, hipMemcpyHostToDevice);
     if (err == hipSuccess) {
