@@ -77,3 +77,22 @@ def test_a_byte_survives_the_round_trip_through_255():
     f32 = np.float32
     for b in range(256):
         assert int(f32(255.0) * f32(f32(b) / f32(255.0))) == b, b
+
+
+def test_packed_strip_row_map_matches_the_reordering_copy():
+    """rm_engine_unpack_bgr_strips_device takes frame row y from packed row
+    ((s % world) * per + s // world) * 8 + y % 8, s = y // 8.  The same rows come out of
+    dist.deinterleave_strips, the re-ordering copy it replaces, for any rank count and height."""
+    import torch
+
+    from raymarching_amd import dist as rdist
+
+    for height in (8, 9, 600, 1080, 2160):
+        for world in (1, 2, 3, 4, 8):
+            _, _, per = rdist.strip_plan(height, 0, world)
+            rows = torch.arange(world * per * 8, dtype=torch.int32).view(world * per * 8, 1, 1).expand(-1, 1, 4).contiguous()
+            ordered = rdist.deinterleave_strips(rows.view(world, per * 8, 1, 4), world, per, 1, height)[:, 0, 0]
+            y = np.arange(height)
+            s = y // 8
+            want = ((s % world) * per + s // world) * 8 + y % 8
+            assert np.array_equal(ordered.numpy(), want), (height, world)
