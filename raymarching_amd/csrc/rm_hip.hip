@@ -375,7 +375,8 @@ __global__ void rad_form_kernel(const RadArgs a, int p0, int p1, int j0, const G
 // (kBounceChunk sources x 64 receivers, receiver-contiguous rows) and the matching emissive
 // values into LDS with many loads in flight, then three waves - one per colour channel - fold the
 // slab in order, one receiver per lane, and the next slab follows.  A pair that contributes nothing
-// (form factor -1) adds +0, which leaves a sum that started at +0 unchanged bit for bit.
+// (form factor -1) enters the slab as 0: its term emission * 0 is +0 (emission values are finite and
+// not negative), which leaves a sum that started at +0 unchanged bit for bit.
 constexpr int kBounceChunk = 64;  // 64 x 64 floats of FT + 64 x 3 emissive floats: 17 KiB of LDS, eight workgroups per CU
 __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0, int p1) {
     __shared__ float slab[kBounceChunk][64];
@@ -396,7 +397,8 @@ __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0
 #pragma unroll
         for (int k = 0; k < kPerThread; k++) {
             const int jj = part + 4 * k;
-            pre[k] = (valid && jj < rows) ? a.ft[(size_t)(j0 + jj) * NP + i] : 0.0f;
+            const float f = (valid && jj < rows) ? a.ft[(size_t)(j0 + jj) * NP + i] : 0.0f;
+            pre[k] = f == -1.0f ? 0.0f : f;  // a pair that contributes nothing: emission * 0 = +0
         }
         em_pre = (int)threadIdx.x < rows * 3 ? a.emissive[3 * j0 + threadIdx.x] : 0.0f;
     };
@@ -410,11 +412,7 @@ __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0
         __syncthreads();
         if (j0 + kBounceChunk < NP) fetch(j0 + kBounceChunk);
         if (part < 3 && valid) {
-            for (int jj = 0; jj < rows; jj++) {
-                const float f = slab[jj][lane];
-                const float term = em_s[3 * jj + part] * f;
-                acc = acc + (f != -1.0f ? term : 0.0f);
-            }
+            for (int jj = 0; jj < rows; jj++) acc = acc + em_s[3 * jj + part] * slab[jj][lane];
         }
         __syncthreads();
     }
