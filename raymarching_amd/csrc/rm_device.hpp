@@ -823,15 +823,25 @@ RM_DEV V3 object_colour(const SceneView &sv, const ShadeRec &sr, const Geom &g, 
     return v3(sr.cr, sr.cg, sr.cb);
 }
 
-RM_DEV V3 luxel(const SceneView &sv, const float *lm, int u, int v, bool &oob) {
+// The four luxels around a sample.  Indices outside the map (the reference aborts on them) are
+// clamped and reported; the check is made once for the four, the clamps only when it fails.
+RM_DEV void luxels4(const SceneView &sv, const float *lm, int u0, int u1, int v0, int v1, bool &oob, V3 &s00, V3 &s01,
+                    V3 &s10, V3 &s11) {
     const int M = sv.map_size;
-    if ((unsigned)u >= (unsigned)M || (unsigned)v >= (unsigned)M) {
-        oob = true;  // the reference aborts on this index
-        u = min(max(u, 0), M - 1);
-        v = min(max(v, 0), M - 1);
+    const unsigned m = (unsigned)M;
+    if (!(((unsigned)u0 < m) & ((unsigned)u1 < m) & ((unsigned)v0 < m) & ((unsigned)v1 < m))) {
+        oob = true;
+        u0 = min(max(u0, 0), M - 1);
+        u1 = min(max(u1, 0), M - 1);
+        v0 = min(max(v0, 0), M - 1);
+        v1 = min(max(v1, 0), M - 1);
     }
-    const float *p = lm + 3 * (u * M + v);
-    return v3(p[0], p[1], p[2]);
+    const float *r0 = lm + 3 * (u0 * M), *r1 = lm + 3 * (u1 * M);
+    const float *p00 = r0 + 3 * v0, *p01 = r0 + 3 * v1, *p10 = r1 + 3 * v0, *p11 = r1 + 3 * v1;
+    s00 = v3(p00[0], p00[1], p00[2]);
+    s01 = v3(p01[0], p01[1], p01[2]);
+    s10 = v3(p10[0], p10[1], p10[2]);
+    s11 = v3(p11[0], p11[1], p11[2]);
 }
 
 // objects.rs:45-133 with colour.rs:47-71 (the two sorts there leave the four
@@ -851,10 +861,8 @@ RM_DEV V3 sample_lightmap(const SceneView &sv, const ShadeRec &sr, const Geom &g
     v1 = (v1 >= M) ? v0 : v1;
 
     bool oob = false;
-    V3 s00 = luxel(sv, lm, u0, v0, oob);
-    V3 s01 = luxel(sv, lm, u0, v1, oob);
-    V3 s10 = luxel(sv, lm, u1, v0, oob);
-    V3 s11 = luxel(sv, lm, u1, v1, oob);
+    V3 s00, s01, s10, s11;
+    luxels4(sv, lm, u0, u1, v0, v1, oob, s00, s01, s10, s11);
 
     bool resample = false;
     if (mag_sqd(s00) == 0.0f) {
@@ -883,12 +891,7 @@ RM_DEV V3 sample_lightmap(const SceneView &sv, const ShadeRec &sr, const Geom &g
             v1 -= 1;
         }
     }
-    if (resample) {
-        s00 = luxel(sv, lm, u0, v0, oob);
-        s01 = luxel(sv, lm, u0, v1, oob);
-        s10 = luxel(sv, lm, u1, v0, oob);
-        s11 = luxel(sv, lm, u1, v1, oob);
-    }
+    if (resample) luxels4(sv, lm, u0, u1, v0, v1, oob, s00, s01, s10, s11);
     if (oob) atomicAdd(&sv.stats[2], 1ULL);
     if (u0 == u1) u1 += 1;
     if (v0 == v1) v1 += 1;
