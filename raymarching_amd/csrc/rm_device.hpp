@@ -844,6 +844,14 @@ RM_DEV void luxels4(const SceneView &sv, const float *lm, int u0, int u1, int v0
     s11 = v3(p11[0], p11[1], p11[2]);
 }
 
+// `mag_sqd() == 0.0` (objects.rs:78-113) without the squares: the sum of three squares is zero exactly
+// when each square rounds to zero, which it does up to |x| = 2^-75 (x * x = 2^-150 lies halfway
+// between 0 and the smallest denormal and goes to the even neighbour, 0).  A NaN fails both forms.
+RM_DEV bool no_light(V3 s) {
+    const float t = 0x1p-75f;
+    return fabsf(s.x) <= t && fabsf(s.y) <= t && fabsf(s.z) <= t;
+}
+
 // objects.rs:45-133 with colour.rs:47-71 (the two sorts there leave the four
 // corners in the order they are passed in, because u0 < u1 and v0 < v1 always).
 RM_DEV V3 sample_lightmap(const SceneView &sv, const ShadeRec &sr, const Geom &g, V3 pos) {
@@ -865,28 +873,28 @@ RM_DEV V3 sample_lightmap(const SceneView &sv, const ShadeRec &sr, const Geom &g
     luxels4(sv, lm, u0, u1, v0, v1, oob, s00, s01, s10, s11);
 
     bool resample = false;
-    if (mag_sqd(s00) == 0.0f) {
+    if (no_light(s00)) {
         resample = true;
-        if (mag_sqd(s10) == 0.0f) {
+        if (no_light(s10)) {
             v0 += 1;
             v1 += 1;
-        } else if (mag_sqd(s11) == 0.0f) {
+        } else if (no_light(s11)) {
             v0 -= 1;
             v1 -= 1;
         }
-        if (mag_sqd(s01) == 0.0f) {
+        if (no_light(s01)) {
             u0 += 1;
             u1 += 1;
-        } else if (mag_sqd(s11) == 0.0f) {
+        } else if (no_light(s11)) {
             u0 -= 1;
             u1 -= 1;
         }
     } else {
-        if (mag_sqd(s10) == 0.0f) {
+        if (no_light(s10)) {
             resample = true;
             u1 -= 1;
         }
-        if (mag_sqd(s01) == 0.0f) {
+        if (no_light(s01)) {
             resample = true;
             v1 -= 1;
         }

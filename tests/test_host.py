@@ -96,3 +96,18 @@ def test_packed_strip_row_map_matches_the_reordering_copy():
             s = y // 8
             want = ((s % world) * per + s // world) * 8 + y % 8
             assert np.array_equal(ordered.numpy(), want), (height, world)
+
+
+def test_sum_of_squares_is_zero_up_to_two_to_the_minus_75():
+    """The kernels test a luxel for `mag_sqd() == 0.0` (objects.rs:78-113) by comparing each component's
+    size with 2^-75: in IEEE f32 a square rounds to zero exactly up to there, and a sum of squares is
+    zero only if every square is."""
+    f32 = np.float32
+    t = f32(2.0 ** -75)
+    around = np.array([np.nextafter(t, f32(0)), t, np.nextafter(t, f32(1)), f32(0), f32(1e-45), f32(2.0 ** -74), f32(1e-30)], dtype=np.float32)
+    for x in around:
+        for y in around:
+            for z in around:
+                with np.errstate(under="ignore"):
+                    zero = f32(f32(f32(x * x) + f32(y * y)) + f32(z * z)) == 0
+                assert zero == (abs(x) <= t and abs(y) <= t and abs(z) <= t), (x, y, z)
