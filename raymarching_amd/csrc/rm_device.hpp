@@ -1145,10 +1145,11 @@ RM_DEV V3 rot(V3 a, float sx, float cx, float sy, float cy) {
 }
 
 // engine.rs:79-84
-RM_DEV V3 pixel_direction(const Pose &p, int x, int y_inv) {
-    int y = p.H - y_inv;
-    float u = 2.0f * ((float)x - (0.5f * (float)p.W)) / (float)p.H;
-    float v = 2.0f * ((float)y - (0.5f * (float)p.H)) / (float)p.H;
+// The screen coordinates u = 2 (x - W/2) / H of a column and v = 2 ((H - y_inv) - H/2) / H of a row
+// depend on the frame size alone: the host tabulates them once per engine in the reference's f32
+// operations, which saves every pixel two divisions.
+RM_DEV V3 pixel_direction(const Pose &p, int x, int y_inv, const float *table_u, const float *table_v) {
+    const float u = table_u[x], v = table_v[y_inv];
     return normalized(rot(v3(u, v, p.zdepth), p.sx, p.cx, p.sy, p.cy));
 }
 

@@ -48,6 +48,7 @@ struct RenderArgs {
     // where that does not apply (scene tiers with a spatial index or smooth unions; a camera closer
     // than SMALL_DISTANCE to something, farther than MAX_MARCH_DISTANCE from everything, or not a number).
     float camera_dist, camera_sph;
+    const float *screen_u, *screen_v;  // [W], [H]: engine.rs:79-82 per column and per row
 };
 
 // Workgroup -> tile.  Tiles are handed out bottom row first: in scenes with a
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderArgs 
     const unsigned long long wave_t0 = wall_clock64();  // 100 MHz
 #endif
     if (x >= a.pose.W || y_inv >= a.row_end) return;
-    V3 dir = pixel_direction(a.pose, x, y_inv);
+    V3 dir = pixel_direction(a.pose, x, y_inv, a.screen_u, a.screen_v);
     V3 cam = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
     diag_lap(DG_SETUP);
     V3 colour = cast_sight_ray(acc_of(g), *a.sv, cam, dir, a.camera_dist, a.camera_sph);
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_ssaa_kernel(const Render
     int x, y_inv, out_row;
     tile_pixel(a, x, y_inv, out_row);
     if (x >= a.pose.W || y_inv >= a.row_end) return;
-    const V3 dir = pixel_direction(a.pose, x, y_inv);
+    const V3 dir = pixel_direction(a.pose, x, y_inv, a.screen_u, a.screen_v);
     const V3 cam = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
     const float ox = 0.5f / (float)a.pose.W, oy = 0.5f / (float)a.pose.H;
     V3 sum = v3(0.0f, 0.0f, 0.0f);
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_tree_kernel(const Render
     int x, y_inv, out_row;
     tile_pixel(a, x, y_inv, out_row);
     if (x >= a.pose.W || y_inv >= a.row_end) return;
-    const V3 dir = pixel_direction(a.pose, x, y_inv);
+    const V3 dir = pixel_direction(a.pose, x, y_inv, a.screen_u, a.screen_v);
     const V3 cam = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
     V3 colour;
     if (samples == 4) {
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_kernel(const RenderArgs a
     int x, y_inv, out_row;
     tile_pixel(a, x, y_inv, out_row);
     if (x >= a.pose.W || y_inv >= a.row_end) return;
-    V3 dir = pixel_direction(a.pose, x, y_inv);
+    V3 dir = pixel_direction(a.pose, x, y_inv, a.screen_u, a.screen_v);
     V3 pos = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
     int steps;
     bool capped;
@@ -671,6 +672,7 @@ struct rm_engine {
     TextureRec *d_tex = nullptr;
     std::vector<float *> d_texels;
     float *d_lightmaps = nullptr;  // [n_patches][3]
+    float *d_screen = nullptr;  // u of every column, then v of every row (engine.rs:79-82)
     unsigned long long *d_stats = nullptr;  // kStatSlots words: RM_STAT_COUNT public ones, the rest for diagnostic builds
     unsigned char *d_frame = nullptr;  // W*H*4, for rm_engine_render
     unsigned char *h_stage = nullptr;  // pinned W*H*4 staging for callers that pass pageable memory
@@ -1122,6 +1124,15 @@ static int engine_upload(rm_engine *e) {
     HIP_TRY(hipMemset(e->d_lightmaps, 0, std::max<size_t>((size_t)e->n_patches * 3, 1) * sizeof(float)));
     HIP_TRY(dev_alloc(&e->d_view, 1));
     e->view_dirty = true;
+    {
+        // engine.rs:79-82: y = HEIGHT - y_inv; u = 2 (x - W/2) / H; v = 2 (y - H/2) / H, in f32 as written
+        std::vector<float> screen((size_t)e->W + e->H);
+        for (int x = 0; x < e->W; x++) screen[x] = 2.0f * ((float)x - (0.5f * (float)e->W)) / (float)e->H;
+        for (int y_inv = 0; y_inv < e->H; y_inv++)
+            screen[(size_t)e->W + y_inv] = 2.0f * ((float)(e->H - y_inv) - (0.5f * (float)e->H)) / (float)e->H;
+        HIP_TRY(dev_alloc(&e->d_screen, screen.size()));
+        HIP_TRY(hipMemcpy(e->d_screen, screen.data(), sizeof(float) * screen.size(), hipMemcpyHostToDevice));
+    }
     HIP_TRY(dev_alloc(&e->d_stats, kStatSlots));
     HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * kStatSlots));
     HIP_TRY(dev_alloc(&e->d_patch_obj, e->n_lm));
@@ -1139,6 +1150,7 @@ static void engine_free(rm_engine *e) {
     for (float *p : e->d_texels) (void)hipFree(p);
     (void)hipFree(e->d_lightmaps);
     (void)hipFree(e->d_stats);
+    (void)hipFree(e->d_screen);
     (void)hipFree(e->d_view);
     (void)hipFree(e->d_frame);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -1228,6 +1240,8 @@ static RenderArgs make_render_args(rm_engine *e, void *d_out, size_t pitch, int 
     a.out = static_cast<unsigned char *>(d_out);
     a.pitch = pitch;
     camera_distances(e, a.camera_dist, a.camera_sph);
+    a.screen_u = e->d_screen;
+    a.screen_v = e->d_screen + e->W;
     grid = dim3((unsigned)(a.blocks_x * a.blocks_y), 1, 1);
     return a;
 }
