@@ -1200,31 +1200,47 @@ static int sync_view(rm_engine *e) {
 }
 
 // The first distance evaluation of every primary march, in the operations of the march loop
-// (objects.rs:261,275,295,315,334): see RenderArgs.
+// (objects.rs:261,275,295,315,334; the box and the smooth minimum as rm_device.hpp defines them):
+// see RenderArgs.  With a smooth union the distances are folded in the march loop's group order -
+// X, Y, Z planes, generic planes, spheres, boxes, by index inside a group.
+static float host_smooth_min(float a, float b, float k) {
+    const float gap = fabsf(a - b);
+    if (gap >= k) return fminf(a, b);
+    float h = fmaxf(k - gap, 0.0f) / k;
+    return fminf(a, b) - h * h * k * (1.0f / 4.0f);
+}
+static float host_box_sdf(const float *c, const float *h, const float *p) {
+    const float qx = fabsf(p[0] - c[0]) - h[0], qy = fabsf(p[1] - c[1]) - h[1], qz = fabsf(p[2] - c[2]) - h[2];
+    const float rx = fmaxf(qx, 0.0f), ry = fmaxf(qy, 0.0f), rz = fmaxf(qz, 0.0f);
+    return sqrtf((rx * rx + ry * ry) + rz * rz) + fminf(fmaxf(qx, fmaxf(qy, qz)), 0.0f);
+}
 static void camera_distances(const rm_engine *e, float &nearest, float &nearest_sphere) {
     nearest = NAN;
     nearest_sphere = INFINITY;
-    if (e->tier > 1 || e->scene.smooth_k > 0.0f) return;  // the by-value scene tiers only
     const float *p = e->pose.cam;
+    const float k = e->scene.smooth_k;
     float d = INFINITY;
-    for (const HostObject &o : e->scene.objects) {
-        float s;
-        switch (o.type) {
-            case T_SPHERE: {
-                const float x = p[0] - o.p[0], y = p[1] - o.p[1], z = p[2] - o.p[2];
-                s = sqrtf((x * x + y * y) + z * z) - o.p[3];
-                nearest_sphere = fminf(nearest_sphere, s);
-                break;
+    static const int group_order[6] = {T_XPLANE, T_YPLANE, T_ZPLANE, T_PLANE, T_SPHERE, T_BOX};
+    for (int group : group_order)
+        for (const HostObject &o : e->scene.objects) {
+            if (o.type != group) continue;
+            float s;
+            switch (o.type) {
+                case T_SPHERE: {
+                    const float x = p[0] - o.p[0], y = p[1] - o.p[1], z = p[2] - o.p[2];
+                    s = sqrtf((x * x + y * y) + z * z) - o.p[3];
+                    nearest_sphere = fminf(nearest_sphere, s);
+                    break;
+                }
+                case T_XPLANE: s = o.p[1] * (p[0] - o.p[0]); break;
+                case T_YPLANE: s = o.p[1] * (p[1] - o.p[0]); break;
+                case T_ZPLANE: s = o.p[1] * (p[2] - o.p[0]); break;
+                case T_PLANE: s = ((p[0] * o.p[0] + p[1] * o.p[1]) + p[2] * o.p[2]) - o.p[3]; break;
+                default: s = host_box_sdf(o.p, o.p + 3, p); break;
             }
-            case T_XPLANE: s = o.p[1] * (p[0] - o.p[0]); break;
-            case T_YPLANE: s = o.p[1] * (p[1] - o.p[0]); break;
-            case T_ZPLANE: s = o.p[1] * (p[2] - o.p[0]); break;
-            case T_PLANE: s = ((p[0] * o.p[0] + p[1] * o.p[1]) + p[2] * o.p[2]) - o.p[3]; break;
-            default: return;  // boxes live in the large tier
+            if (!(s == s)) return;
+            d = k > 0.0f ? host_smooth_min(d, s, k) : fminf(d, s);
         }
-        if (!(s == s)) return;
-        d = fminf(d, s);
-    }
     if (d >= SMALL_DISTANCE && d < MAX_MARCH_DISTANCE) nearest = d;
 }
 
