@@ -44,9 +44,9 @@ struct RenderArgs {
     size_t pitch;
     // Every primary ray starts at the camera, so the first distance evaluation of every primary march
     // is the same: the host makes it once per frame.  camera_dist = distance from the camera to the
-    // nearest object, camera_sph = to the nearest sphere (+inf without spheres); camera_dist is NaN
-    // where that does not apply (scene tiers with a spatial index or smooth unions; a camera closer
-    // than SMALL_DISTANCE to something, farther than MAX_MARCH_DISTANCE from everything, or not a number).
+    // nearest object (the smooth fold where the scene has one), camera_sph = to the nearest sphere
+    // (+inf without spheres); camera_dist is NaN where that does not apply (a camera closer than
+    // SMALL_DISTANCE to something, farther than MAX_MARCH_DISTANCE from everything, or not a number).
     float camera_dist, camera_sph;
     const float *screen_u, *screen_v;  // [W], [H]: engine.rs:79-82 per column and per row
 };
