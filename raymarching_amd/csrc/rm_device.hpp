@@ -425,8 +425,15 @@ RM_DEV bool grid_fold(const SC &sc, V3 p, const IGN &ign, float &r, float k, boo
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (e + u < c.s1) {
-                const float s = sqrt_rn(mag_sqd(p - v3(g[u].x, g[u].y, g[u].z))) - g[u].w;
-                fold(ign.skip(oi[u]) ? __builtin_inff() : ign.mask(oi[u], s));
+                // A primitive at least k beyond the running value (hard minimum: at or beyond it) changes
+                // nothing: the smooth minimum returns the running value, which is never more than k
+                // above floor_before, so neither of the other two lines of `fold` acts either.  The
+                // one-ulp square root decides that for most entries; `far` covers its distance from the
+                // rounded one (below 1e-6 of the root).
+                const float m = mag_sqd(p - v3(g[u].x, g[u].y, g[u].z));
+                const float rough = __builtin_amdgcn_sqrtf(m) - g[u].w;
+                const float far = (blend ? r + k : r) + 2e-6f * (rough + 2.0f * fabsf(g[u].w)) + 1e-6f;
+                if (!(rough > far) && !ign.skip(oi[u])) fold(ign.mask(oi[u], sqrt_rn(m) - g[u].w));
             }
         }
     }
@@ -443,8 +450,11 @@ RM_DEV bool grid_fold(const SC &sc, V3 p, const IGN &ign, float &r, float k, boo
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             if (e + u < c.b1) {
-                const float s = box_sdf(v3(g0[u].x, g0[u].y, g0[u].z), v3(g0[u].w, g1[u].x, g1[u].y), p);
-                fold(ign.skip(oi[u]) ? __builtin_inff() : ign.mask(oi[u], s));
+                // the same for a box: outside it, its distance is at least the largest of the three
+                // face distances (the box's own subtractions; the margin covers the rounding of its root)
+                const V3 bc = v3(g0[u].x, g0[u].y, g0[u].z), bh = v3(g0[u].w, g1[u].x, g1[u].y);
+                const float face = rs_max(fabsf(p.x - bc.x) - bh.x, rs_max(fabsf(p.y - bc.y) - bh.y, fabsf(p.z - bc.z) - bh.z));
+                if (!(face > (blend ? r + k : r) + 2e-6f * face + 1e-6f) && !ign.skip(oi[u])) fold(ign.mask(oi[u], box_sdf(bc, bh, p)));
             }
         }
     }
