@@ -536,7 +536,11 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, LaneMask act, SphereB
         sb.T = __builtin_fmaf(travelled, sb.dn, nearest - sb.M);
     }
     sc.boxes([&](int oi, V3 c, V3 h) {
-        if (!ign.skip(oi)) fold(ign.mask(oi, box_sdf(c, h, p)));
+        if (ign.skip(oi)) return;
+        // a box whose largest face distance lies k beyond the running value (hard minimum: beyond
+        // it) cannot change the result: its distance is at least that, the margin covers its root
+        const float face = rs_max(fabsf(p.x - c.x) - h.x, rs_max(fabsf(p.y - c.y) - h.y, fabsf(p.z - c.z) - h.z));
+        if (!(face > (blend ? d + k : d) + 2e-6f * face + 1e-6f)) fold(ign.mask(oi, box_sdf(c, h, p)));
     });
     return d;
 }
