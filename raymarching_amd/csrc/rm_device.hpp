@@ -409,10 +409,42 @@ RM_DEV bool grid_fold(const SC &sc, V3 p, const IGN &ign, float &r, float k, boo
             r = rs_min(r, s);
         }
     };
-    // Entries are fetched four (boxes: two) at a time before any is used, so that a list costs one
-    // memory round trip per group instead of one per entry; they are folded one by one, in order.
+    // A primitive at least k beyond the running value (hard minimum: at or beyond it) changes nothing:
+    // the smooth minimum returns the running value, which is never more than k above floor_before, so
+    // neither of the other two lines of `fold` acts either.  The one-ulp square root decides that for
+    // most entries; `far` covers its distance from the rounded one (below 1e-6 of the root).  For a
+    // box, its distance outside is at least the largest of its three face distances.
+    auto sphere_entry = [&](float cx, float cy, float cz, float rad, int oi) {
+        const float m = mag_sqd(p - v3(cx, cy, cz));
+        const float rough = __builtin_amdgcn_sqrtf(m) - rad;
+        const float far = (blend ? r + k : r) + 2e-6f * (rough + 2.0f * fabsf(rad)) + 1e-6f;
+        if (!(rough > far) && !ign.skip(oi)) fold(ign.mask(oi, sqrt_rn(m) - rad));
+    };
+    auto box_entry = [&](V3 bc, V3 bh, int oi) {
+        const float face = rs_max(fabsf(p.x - bc.x) - bh.x, rs_max(fabsf(p.y - bc.y) - bh.y, fabsf(p.z - bc.z) - bh.z));
+        if (!(face > (blend ? r + k : r) + 2e-6f * face + 1e-6f) && !ign.skip(oi)) fold(ign.mask(oi, box_sdf(bc, bh, p)));
+    };
     const ConstFloat4s sph_geom = (ConstFloat4s)lv.sph_geom, box_geom = (ConstFloat4s)lv.box_geom;
     const ConstInts sph_index = constant(lv.sph_index), box_index = constant(lv.box_index);
+    // The pixels of a tile mostly sit in one cell.  A wave whose lanes all do walks the lists with
+    // wave-uniform indices: the entries arrive by scalar loads, once per wave, and no lane waits for
+    // another's longer list.
+    const int us0 = __builtin_amdgcn_readfirstlane(c.s0), us1 = __builtin_amdgcn_readfirstlane(c.s1);
+    const int ub0 = __builtin_amdgcn_readfirstlane(c.b0), ub1 = __builtin_amdgcn_readfirstlane(c.b1);
+    if (wave_all(c.s0 == us0 && c.s1 == us1 && c.b0 == ub0 && c.b1 == ub1)) {
+        for (int e = us0; e < us1; e++) {
+            const Float4 g = sph_geom[e];
+            sphere_entry(g.x, g.y, g.z, g.w, sph_index[e]);
+        }
+        for (int e = ub0; e < ub1; e++) {
+            const Float4 g0 = box_geom[2 * e], g1 = box_geom[2 * e + 1];
+            box_entry(v3(g0.x, g0.y, g0.z), v3(g0.w, g1.x, g1.y), box_index[e]);
+        }
+        return blend ? certain : (r <= R);
+    }
+    // Otherwise every lane walks its own lists.  Entries are fetched four (boxes: two) at a time
+    // before any is used, so that a list costs one memory round trip per group instead of one per
+    // entry; they are folded one by one, in order.
     for (int e = c.s0; e < c.s1; e += 4) {
         Float4 g[4];
         int oi[4];
@@ -423,19 +455,8 @@ RM_DEV bool grid_fold(const SC &sc, V3 p, const IGN &ign, float &r, float k, boo
             oi[u] = sph_index[ee];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (e + u < c.s1) {
-                // A primitive at least k beyond the running value (hard minimum: at or beyond it) changes
-                // nothing: the smooth minimum returns the running value, which is never more than k
-                // above floor_before, so neither of the other two lines of `fold` acts either.  The
-                // one-ulp square root decides that for most entries; `far` covers its distance from the
-                // rounded one (below 1e-6 of the root).
-                const float m = mag_sqd(p - v3(g[u].x, g[u].y, g[u].z));
-                const float rough = __builtin_amdgcn_sqrtf(m) - g[u].w;
-                const float far = (blend ? r + k : r) + 2e-6f * (rough + 2.0f * fabsf(g[u].w)) + 1e-6f;
-                if (!(rough > far) && !ign.skip(oi[u])) fold(ign.mask(oi[u], sqrt_rn(m) - g[u].w));
-            }
-        }
+        for (int u = 0; u < 4; u++)
+            if (e + u < c.s1) sphere_entry(g[u].x, g[u].y, g[u].z, g[u].w, oi[u]);
     }
     for (int e = c.b0; e < c.b1; e += 2) {
         Float4 g0[2], g1[2];
@@ -448,15 +469,8 @@ RM_DEV bool grid_fold(const SC &sc, V3 p, const IGN &ign, float &r, float k, boo
             oi[u] = box_index[ee];
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            if (e + u < c.b1) {
-                // the same for a box: outside it, its distance is at least the largest of the three
-                // face distances (the box's own subtractions; the margin covers the rounding of its root)
-                const V3 bc = v3(g0[u].x, g0[u].y, g0[u].z), bh = v3(g0[u].w, g1[u].x, g1[u].y);
-                const float face = rs_max(fabsf(p.x - bc.x) - bh.x, rs_max(fabsf(p.y - bc.y) - bh.y, fabsf(p.z - bc.z) - bh.z));
-                if (!(face > (blend ? r + k : r) + 2e-6f * face + 1e-6f) && !ign.skip(oi[u])) fold(ign.mask(oi[u], box_sdf(bc, bh, p)));
-            }
-        }
+        for (int u = 0; u < 2; u++)
+            if (e + u < c.b1) box_entry(v3(g0[u].x, g0[u].y, g0[u].z), v3(g0[u].w, g1[u].x, g1[u].y), oi[u]);
     }
     return blend ? certain : (r <= R);
 }
