@@ -360,8 +360,19 @@ RM_DEV CellLists grid_cell(const GridView &gv, const GridLevel &lv, V3 p) {
     const float fx = (p.x - gv.ox) * gv.inv_cell, fy = (p.y - gv.oy) * gv.inv_cell, fz = (p.z - gv.oz) * gv.inv_cell;
     const bool inside = fx >= 0.0f && fx < (float)gv.nx && fy >= 0.0f && fy < (float)gv.ny && fz >= 0.0f && fz < (float)gv.nz;
     CellLists c = {0, 0, 0, 0, gv.reach};
+    const int cell = inside ? ((int)fz * gv.ny + (int)fy) * gv.nx + (int)fx : -1;  // non-negative: truncation is floor
+    const int ucell = __builtin_amdgcn_readfirstlane(cell);
+    if (ucell >= 0 && wave_all(cell == ucell)) {
+        // every lane in the same cell (the usual case for a tile): its record comes by a scalar load
+        const Int4 rec = ((ConstInt4s)lv.cell)[ucell];
+        c.s0 = rec.x;
+        c.s1 = rec.x + (rec.z & 0xffff);
+        c.b0 = rec.y;
+        c.b1 = rec.y + ((unsigned)rec.z >> 16);
+        c.reach = __int_as_float(rec.w);
+        return c;
+    }
     if (inside) {
-        const int cell = ((int)fz * gv.ny + (int)fy) * gv.nx + (int)fx;  // non-negative: truncation is floor
         const Int4 rec = ((ConstInt4s)lv.cell)[cell];  // one 16-byte record: first sphere, first box, counts, reach
         c.s0 = rec.x;
         c.s1 = rec.x + (rec.z & 0xffff);
@@ -387,10 +398,9 @@ RM_DEV CellLists grid_cell(const GridView &gv, const GridLevel &lv, V3 p) {
 //     more than k below the minimum of what was folded, so at that turn the gap is >= k in both
 //     folds, both take exactly s (<= R - 2k), and from there on they agree.  (`slack` keeps the
 //     comparison clear of the rounding of the two sums.)
-template <int LEVEL, class SC, class IGN>
-RM_DEV bool grid_fold(const SC &sc, V3 p, const IGN &ign, float &r, float k, bool blend) {
+template <class SC, class IGN>
+RM_DEV bool grid_fold(const SC &sc, const GridLevel &lv, V3 p, const IGN &ign, float &r, float k, bool blend) {
     const GridView &gv = sc.grid();
-    const GridLevel &lv = gv.level[LEVEL];
     const CellLists c = grid_cell(gv, lv, p);
     const float R = c.reach;
     bool certain = r <= R - k;  // blend only
@@ -411,14 +421,15 @@ RM_DEV bool grid_fold(const SC &sc, V3 p, const IGN &ign, float &r, float k, boo
     };
     // A primitive at least k beyond the running value (hard minimum: at or beyond it) changes nothing:
     // the smooth minimum returns the running value, which is never more than k above floor_before, so
-    // neither of the other two lines of `fold` acts either.  The one-ulp square root decides that for
-    // most entries; `far` covers its distance from the rounded one (below 1e-6 of the root).  For a
-    // box, its distance outside is at least the largest of its three face distances.
+    // neither of the other two lines of `fold` acts either.  For a sphere the squared centre distance
+    // decides that for most entries, without a square root; for a box, its distance outside is at least
+    // the largest of its three face distances.
     auto sphere_entry = [&](float cx, float cy, float cz, float rad, int oi) {
         const float m = mag_sqd(p - v3(cx, cy, cz));
-        const float rough = __builtin_amdgcn_sqrtf(m) - rad;
-        const float far = (blend ? r + k : r) + 2e-6f * (rough + 2.0f * fabsf(rad)) + 1e-6f;
-        if (!(rough > far) && !ign.skip(oi)) fold(ign.mask(oi, sqrt_rn(m) - rad));
+        // centre distance beyond (running value [+ k]) + radius, compared in squares: `m` is within
+        // 4e-7 of the true square, the rounded root within 6e-8 of the true root, the margin is 1e-5
+        const float beyond = rs_max((blend ? r + k : r) + rad, 0.0f) * 1.00001f + 1e-6f;
+        if (!(m > beyond * beyond) && !ign.skip(oi)) fold(ign.mask(oi, sqrt_rn(m) - rad));
     };
     auto box_entry = [&](V3 bc, V3 bh, int oi) {
         const float face = rs_max(fabsf(p.x - bc.x) - bh.x, rs_max(fabsf(p.y - bc.y) - bh.y, fabsf(p.z - bc.z) - bh.z));
@@ -520,11 +531,13 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, LaneMask act, SphereB
             if (!active) return d;
             // the cell's short lists first, its long lists if those leave the value open, and the
             // full walk below if these do too
-            float r = d;
+            // (one copy of the fold in the code, run for one level after the other)
             diag_event(6);
-            if (grid_fold<0>(sc, p, ign, r, k, blend)) return r;
-            r = d;
-            if (grid_fold<1>(sc, p, ign, r, k, blend)) return r;
+#pragma nounroll
+            for (int level = 0; level < kGridLevels; level++) {
+                float r = d;
+                if (grid_fold(sc, sc.grid().level[level], p, ign, r, k, blend)) return r;
+            }
             diag_event(7);
         }
     }
@@ -704,6 +717,8 @@ RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, in
 template <class SC>
 RM_DEV int march(const SC &sc, V3 &pos, V3 dir, int ignore, int cap, int &steps, bool &capped,
                  float first = __builtin_nanf(""), float first_sph = __builtin_nanf("")) {
+    // (the large layout keeps one copy of the loops: its code would not fit the instruction cache threefold)
+    if constexpr (SC::kGrid) return march_with(sc, pos, dir, LaneIgnore{ignore}, cap, steps, capped, first, first_sph);
     const int u = __builtin_amdgcn_readfirstlane(ignore);
     if (wave_all(ignore == u)) {
         if (u < 0) return march_with(sc, pos, dir, NoIgnore{}, cap, steps, capped, first, first_sph);
@@ -753,6 +768,7 @@ template <class SC>
 RM_DEV float smooth_shadow_march(const SC &sc, V3 pos, V3 dir, int ignore, float light_dist, float k, bool wanted = true) {
     const LaneMask want = __builtin_amdgcn_ballot_w64(wanted);
     if (want == 0) return 1.0f;
+    if constexpr (SC::kGrid) return shadow_with(sc, pos, dir, LaneIgnore{ignore}, light_dist, k, want);
     const int u = __builtin_amdgcn_readfirstlane(ignore);
     if (wave_all(ignore == u)) return shadow_with(sc, pos, dir, UniformIgnore{u}, light_dist, k, want);
     return shadow_with(sc, pos, dir, LaneIgnore{ignore}, light_dist, k, want);
