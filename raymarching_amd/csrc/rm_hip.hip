@@ -636,9 +636,9 @@ constexpr int kDefaultBands = 4;  // measured best at 3840x2160: more bands add 
 constexpr size_t kBandedFramePixels = 4u << 20;  // smaller frames leave in one piece: their bands would each wait for a slow tile
 constexpr int kGridMinPrimitives = 16;  // fewer bounded primitives than this: no spatial index
 constexpr int kGridMaxDim = 48;         // cells per axis at most
-constexpr int kGridMinList = 6;         // a cell lists at least this many primitives (its reach grows to admit them)
+constexpr int kGridMinList = 16;        // a cell lists at least this many primitives (its reach grows to admit them)
 constexpr int kGridMaxList = 48;        // and at most this many (its reach shrinks)
-constexpr int kGridShortList = 4;       // the short lists tried first: this many nearest primitives per cell
+constexpr int kGridShortList = 8;       // the short lists tried first: this many nearest primitives per cell
 
 struct rm_engine {
     int device = 0;
