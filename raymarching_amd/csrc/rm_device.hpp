@@ -656,7 +656,10 @@ RM_DEV int march_capped(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, 
         travelled += d;
         pos = pos + dir * d;
     }
-    return hit ? closest_index(sc, pos, d, ign, lanes_in(sb.spheres_out)) : -1;
+    // Lanes leave the loop above at different times, so the wave-wide mask sb.spheres_out holds, for a
+    // lane, whatever the lanes still running wrote after it left: it is not consulted here, and every
+    // object is evaluated for the hit.
+    return hit ? closest_index(sc, pos, d, ign, false) : -1;
 }
 
 // The same loop for the usual case of no iteration cap, written so that the wave

@@ -956,11 +956,22 @@ static int engine_upload(rm_engine *e) {
                 // reach instead of a full walk; kGridMaxList caps a list by lowering the cell's reach.
                 const double vol = std::max(ex[0], 0.05 * longest) * std::max(ex[1], 0.05 * longest) * std::max(ex[2], 0.05 * longest);
                 const double spacing = std::cbrt(vol / n_bounded);
-                const double reach_mul = getenv("RM_GRID_REACH") ? atof(getenv("RM_GRID_REACH")) : 0.85;  // tuning aids
-                const double cell_mul = getenv("RM_GRID_CELL") ? atof(getenv("RM_GRID_CELL")) : 0.25;
-                const int min_list = getenv("RM_GRID_MINLIST") ? atoi(getenv("RM_GRID_MINLIST")) : kGridMinList;
-                const int max_list = getenv("RM_GRID_MAXLIST") ? atoi(getenv("RM_GRID_MAXLIST")) : kGridMaxList;
-                const int short_list = getenv("RM_GRID_SHORTLIST") ? atoi(getenv("RM_GRID_SHORTLIST")) : kGridShortList;
+                // (the environment overrides are tuning aids; values outside the ranges the lists and the
+                // 16-bit counts of a cell record can hold are brought inside them)
+                const auto env_mul = [](const char *name, double dflt) {
+                    const char *v = getenv(name);
+                    const double x = v ? atof(v) : dflt;
+                    return (x >= 0.01 && x <= 100.0) ? x : dflt;  // also refuses NaN
+                };
+                const auto env_count = [&](const char *name, int dflt) {
+                    const char *v = getenv(name);
+                    return std::max(1, std::min({v ? atoi(v) : dflt, n_bounded, 65535}));
+                };
+                const double reach_mul = env_mul("RM_GRID_REACH", 0.85);
+                const double cell_mul = env_mul("RM_GRID_CELL", 0.25);
+                const int min_list = env_count("RM_GRID_MINLIST", kGridMinList);
+                const int max_list = std::max(min_list, env_count("RM_GRID_MAXLIST", kGridMaxList));
+                const int short_list = env_count("RM_GRID_SHORTLIST", kGridShortList);
                 const float reach = (float)(reach_mul * spacing + 2.0 * s.smooth_k);
                 // the grid spans the primitives and half their extent around them; beyond it every
                 // primitive is at least `apron` away
@@ -1189,9 +1200,20 @@ static void engine_free(rm_engine *e) {
                                (e)->large_scene);                                                             \
     } while (0)
 
-// Brings the device copy of the SceneView up to date (stream ordered).
+// Waits for the frames of rm_engine_render_async that are still rendering or on their way to the
+// host (they stay pending for rm_engine_render_wait): what they read - the SceneView, the lightmaps -
+// is about to change.
+static int quiesce_frames_in_flight(rm_engine *e) {
+    for (int i = 0; i < RM_FRAMES_IN_FLIGHT; i++)
+        if (e->async_pending[i] && e->slot_stream[i]) HIP_TRY(hipStreamSynchronize(e->slot_stream[i]));
+    return RM_OK;
+}
+
+// Brings the device copy of the SceneView up to date (stream ordered).  There is one copy for all
+// frames: a change of settings first lets the frames in flight finish with the old one.
 static int sync_view(rm_engine *e) {
     if (!e->view_dirty) return RM_OK;
+    if (int rc_ = quiesce_frames_in_flight(e)) return rc_;
     e->h_view = e->view();
     HIP_TRY(hipMemcpyAsync(e->d_view, &e->h_view, sizeof(SceneView), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));  // h_view may change before an async copy would read it
@@ -1753,6 +1775,7 @@ int rm_engine_radiosity_begin(rm_engine *e) {
     if (!e) return fail(RM_ERR_INVALID, "NULL engine");
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_ = sync_view(e)) return rc_;
+    if (int rc_ = quiesce_frames_in_flight(e)) return rc_;  // the precompute rewrites the lightmaps they sample
     const int NP = e->n_patches, M = e->M;
     if (!e->d_pos) {
         HIP_TRY(dev_alloc(&e->d_pos, (size_t)NP * 3));
@@ -1880,6 +1903,7 @@ int rm_engine_set_lightmap(rm_engine *e, int object, const float *values) {
     if (int rc_ = sync_view(e)) return rc_;
     size_t count = (size_t)e->M * e->M * 3;
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (int rc_ = quiesce_frames_in_flight(e)) return rc_;  // frames in flight still sample the old values
     HIP_TRY(hipMemcpy(e->d_lightmaps + slot * count, values, count * sizeof(float), hipMemcpyHostToDevice));
     return RM_OK;
 }

@@ -127,10 +127,13 @@ def compute_lightmaps_sharded(engine, bounces: int = 4, group=None):
         engine.radiosity_bounce(p0, p1)
         engine.synchronize()
         emissive.copy_(gather_patches(emissive[p0:p1].clone(), n, group))
+        # the gathered values were written on torch's current stream, the commit reads them on the
+        # engine's: whatever the two are, the copy has to have landed first
+        torch.cuda.current_stream().synchronize()
         engine.radiosity_commit()
     engine.synchronize()
     lightmaps.copy_(gather_patches(lightmaps[p0:p1].clone(), n, group))
-    torch.cuda.synchronize()
+    torch.cuda.current_stream().synchronize()
     engine.synchronize()
 
 

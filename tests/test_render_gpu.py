@@ -352,6 +352,51 @@ def test_frame_sequence_with_recorded_input(scene, oracle_lightmaps):
     eng.close()
 
 
+def test_settings_change_between_frames_in_flight(scene, oracle_lightmaps):
+    """Switches and lightmaps changed between two rm_engine_render_async frames: the frame already in
+    flight keeps what it was submitted with (there is one device copy of the settings for all frames),
+    the next one gets the new values.  Each frame is compared with a synchronous render at its settings."""
+    import ctypes
+
+    from raymarching_amd import Engine, _lib
+
+    w, h = 1920, 1080  # large enough for frame 1 to be still rendering when the switch is flipped
+    lm, _ = oracle_lightmaps
+    eng = Engine(scene, w, h)
+    for i in range(eng.n_objects):
+        eng.set_lightmap(i, lm[-1][i])
+    plain = eng.render()
+    eng.set_refraction(True)
+    refr = eng.render()
+    eng.set_refraction(False)
+    for i in range(eng.n_objects):
+        eng.set_lightmap(i, lm[1][i])  # after one bounce: darker
+    dark = eng.render()
+    for i in range(eng.n_objects):
+        eng.set_lightmap(i, lm[-1][i])
+    assert not np.array_equal(plain, refr) and not np.array_equal(plain, dark)
+    lib = _lib.load()
+    n_bytes = w * h * 4
+    bufs = [lib.rm_host_alloc(n_bytes) for _ in range(2)]
+    views = [np.ctypeslib.as_array((ctypes.c_uint8 * n_bytes).from_address(b)).reshape(h, w, 4) for b in bufs]
+    for second, change, undo in (
+        (refr, lambda: eng.set_refraction(True), lambda: eng.set_refraction(False)),
+        (dark, lambda: [eng.set_lightmap(i, lm[1][i]) for i in range(eng.n_objects)],
+         lambda: [eng.set_lightmap(i, lm[-1][i]) for i in range(eng.n_objects)]),
+    ):
+        eng.render_async(bufs[0])
+        change()
+        eng.render_async(bufs[1])
+        eng.render_wait()
+        eng.render_wait()
+        assert np.array_equal(views[0], plain)
+        assert np.array_equal(views[1], second)
+        undo()
+    for b in bufs:
+        lib.rm_host_free(b)
+    eng.close()
+
+
 def test_tone_map_estimate_never_disagrees_with_the_exact_operations(gpu_engine):
     """engine.rs:109-125: the frames pack a pixel from one-ulp estimates of the division and the
     square root and take the exact operations only near a rounding boundary.  Both paths side by side

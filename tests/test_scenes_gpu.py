@@ -190,3 +190,34 @@ def test_march_cap_counts_and_binds(scene):
     hit2, steps2, _ = eng.trace_primary()
     assert (hit2 >= 0).all() and steps2.max() > 6
     eng.close()
+
+
+@pytest.mark.parametrize("cap", [40, 100000])
+def test_capped_march_matches_oracle(scene, cap):
+    """The march with an iteration cap (the loop whose lanes leave one by one) against the oracle's
+    uncapped march: wherever the oracle needs at most `cap` iterations the hit object, the iteration
+    count and the end position are the oracle's bit for bit; everywhere else the march reports no hit
+    after exactly `cap` iterations.  A frame rendered under a cap that never binds is the frame
+    without a cap."""
+    from raymarching_amd import Engine
+
+    w, h = 400, 300
+    ora = make_oracle(scene)
+    hit_o, steps_o, pos_o = ora.trace_primary(w, h)
+    ora.close()
+    eng = Engine(scene, w, h)
+    eng.compute_lightmaps(4)
+    plain = eng.render()
+    eng.set_march_cap(cap)
+    hit_g, steps_g, pos_g = eng.trace_primary()
+    within = steps_o <= cap
+    assert within.any()
+    assert np.array_equal(hit_g[within], hit_o[within])
+    assert np.array_equal(steps_g[within], steps_o[within])
+    assert np.array_equal(pos_g[within].view(np.uint32), pos_o[within].view(np.uint32))
+    assert (hit_g[~within] == -1).all() and (steps_g[~within] == cap).all()
+    if within.all():
+        capped_frame = eng.render()
+        assert np.array_equal(capped_frame, plain)
+        assert eng.stats()["step_cap_hits"] == 0
+    eng.close()
