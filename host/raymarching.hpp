@@ -186,6 +186,8 @@ class Engine {
 
     // engine.rs:246
     void compute_lightmaps(int bounces = 4) { check(rm_engine_compute_lightmaps(handle_, bounces), "compute_lightmaps"); }
+    // the same without any device allocation (work buffers in the library's static array; at most RM_STATIC_MAX_PATCHES patches)
+    void compute_lightmaps_static(int bounces = 4) { check(rm_engine_compute_lightmaps_static(handle_, bounces), "compute_lightmaps_static"); }
 
     // engine.rs:38-41 (the `directions` scratch argument of the reference is gone)
     void render(uint8_t *buffer, size_t pitch, int32_t mouse_x, int32_t mouse_y, Vec3 rel_move, int32_t scroll) {

@@ -150,6 +150,17 @@ int rm_engine_radiosity_bounce(rm_engine *engine, int p0, int p1);
 int rm_engine_radiosity_commit(rm_engine *engine);
 int rm_engine_radiosity_buffers(rm_engine *engine, void **d_next_emissive, void **d_lightmaps, int *n_patches);
 
+/* rm_engine_compute_lightmaps for callers that cannot allocate device memory (code under HIP graph
+ * capture set-up, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same kernels, same result bit for bit; the clouds, the emissive maps and the
+ * form-factor matrix live in a static device array of the library (4.05 MiB per GPU, held until the
+ * process ends) instead of buffers allocated on first use, and the call allocates nothing.
+ * Limit: map_size^2 * lightmapped objects <= RM_STATIC_MAX_PATCHES, else RM_ERR_LIMIT.  Every engine
+ * on one GPU shares that GPU's array: calls that overlap on one GPU race (calls on different GPUs do
+ * not).  The stepwise rm_engine_radiosity_* entry points keep using the engine's own buffers. */
+#define RM_STATIC_MAX_PATCHES 1024
+int rm_engine_compute_lightmaps_static(rm_engine *engine, int bounces);
+
 /* EngineObject::get_lightmap / set_lightmap (objects.rs:34-35,216-217):
  * `values` is [map_size][map_size][3] float, first index u (as sample_map[u][v]). */
 int rm_engine_get_lightmap(rm_engine *engine, int object, float *values);

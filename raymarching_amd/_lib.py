@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librm_hip.so")
 
 RM_STAT_COUNT = 8
+RM_STATIC_MAX_PATCHES = 1024
 STAT_NAMES = ("depth_cap_hits", "step_cap_hits", "lightmap_oob", "texture_oob")
 
 
@@ -42,6 +43,7 @@ SIGNATURES = {
     "rm_engine_destroy": (None, [c_void_p]),
     "rm_engine_set_stream": (c_int, [c_void_p, c_void_p]),
     "rm_engine_compute_lightmaps": (c_int, [c_void_p, c_int]),
+    "rm_engine_compute_lightmaps_static": (c_int, [c_void_p, c_int]),
     "rm_engine_radiosity_begin": (c_int, [c_void_p]),
     "rm_engine_radiosity_form_factors": (c_int, [c_void_p, c_int, c_int]),
     "rm_engine_radiosity_bounce": (c_int, [c_void_p, c_int, c_int]),

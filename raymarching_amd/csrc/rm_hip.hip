@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -260,6 +261,13 @@ __global__ void probe_pack_kernel(int n, const float *linear, float exposure, un
 }
 
 // ---- radiosity -------------------------------------------------------------
+
+// Device memory the lightmap precompute works in besides the scene and the lightmaps themselves.
+struct RadBuffers {
+    float *col = nullptr, *nrm = nullptr;                      // [NP][3] clouds (engine.rs:274-281)
+    float *emissive = nullptr, *emissive_next = nullptr;       // [NP][3]
+    float *ft = nullptr;                                       // [NP][NP] form factors
+};
 
 struct RadArgs {
     const SceneView *sv;
@@ -593,6 +601,34 @@ __global__ __launch_bounds__(256) void unpack_bgr_strips_kernel(const unsigned *
 // Host runtime
 // ===========================================================================
 
+// Static scratch for rm_engine_compute_lightmaps_static: four [NP][3] float arrays (each rounded up
+// to 64 floats) and the [NP][NP] form-factor matrix for NP <= RM_STATIC_MAX_PATCHES.  Every GPU the
+// library runs on holds its own copy (4.05 MiB) at its own address until the process ends.  In host
+// code the name below is only a handle for hipGetSymbolAddress: the address kernels and memsets are
+// given is the one static_scratch_of() returns for the current device.
+constexpr size_t kStaticCloudFloats = ((size_t)RM_STATIC_MAX_PATCHES * 3 + 63) & ~(size_t)63;
+constexpr size_t kStaticScratchFloats = 4 * kStaticCloudFloats + (size_t)RM_STATIC_MAX_PATCHES * RM_STATIC_MAX_PATCHES;
+static __device__ __align__(256) float scratch[kStaticScratchFloats];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static float *g_scratch_ptr[kMaxDevices];  // per device, looked up once
+
+// The address of `scratch` on `device`, which must be the current device.
+static hipError_t static_scratch_of(int device, float **out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        hipError_t err = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (err != hipSuccess) return err;
+        g_scratch_ptr[device] = static_cast<float *>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 static thread_local std::string g_error;
 
 static int fail(int code, const std::string &msg) {
@@ -693,10 +729,11 @@ struct rm_engine {
 
     // radiosity work buffers
     int *d_patch_obj = nullptr;
-    float *d_pos = nullptr, *d_col = nullptr, *d_nrm = nullptr;
-    float *d_emissive = nullptr, *d_emissive_next = nullptr;
-    float *d_ft = nullptr;
+    RadBuffers rad;  // allocated by rm_engine_radiosity_begin / _form_factors
     bool rad_begun = false;
+    float *d_sample_pos = nullptr;  // [n_patches][3]: the point cloud of engine.rs:269-273, uploaded at creation
+    bool sample_pos_ok = false;     // false: some lightmapped type has no sample positions
+    float *scratch = nullptr;  // this device's copy of the library's static scratch array
 
     SceneView view() const {
         SceneView sv;
@@ -718,18 +755,18 @@ struct rm_engine {
         sv.stats = d_stats;
         return sv;
     }
-    RadArgs rad_args() const {
+    RadArgs rad_args(const RadBuffers &b) const {
         RadArgs a;
         a.sv = d_view;
         a.n_patches = n_patches;
         a.patch_obj = d_patch_obj;
-        a.pos = d_pos;
-        a.col = d_col;
-        a.nrm = d_nrm;
-        a.emissive = d_emissive;
-        a.emissive_next = d_emissive_next;
+        a.pos = d_sample_pos;
+        a.col = b.col;
+        a.nrm = b.nrm;
+        a.emissive = b.emissive;
+        a.emissive_next = b.emissive_next;
         a.lightmaps = d_lightmaps;
-        a.ft = d_ft;
+        a.ft = b.ft;
         return a;
     }
 };
@@ -1149,6 +1186,20 @@ static int engine_upload(rm_engine *e) {
     HIP_TRY(dev_alloc(&e->d_patch_obj, e->n_lm));
     if (e->n_lm)
         HIP_TRY(hipMemcpy(e->d_patch_obj, e->patch_obj.data(), sizeof(int) * e->n_lm, hipMemcpyHostToDevice));
+    {
+        // engine.rs:269-273: the world position of every sample point (sin/cos stay on the host)
+        const int M = e->M;
+        std::vector<float> pos((size_t)e->n_patches * 3);
+        bool ok = true;
+        for (int ci = 0; ci < e->n_lm && ok; ci++) {
+            const HostObject &o = s.objects[e->patch_obj[ci]];
+            for (int x = 0; x < M && ok; x++)
+                for (int y = 0; y < M && ok; y++) ok = host_sample_pos(o, M, x, y, &pos[((size_t)(ci * M + x) * M + y) * 3]);
+        }
+        e->sample_pos_ok = ok;
+        HIP_TRY(dev_alloc(&e->d_sample_pos, pos.size()));
+        if (ok && !pos.empty()) HIP_TRY(hipMemcpy(e->d_sample_pos, pos.data(), sizeof(float) * pos.size(), hipMemcpyHostToDevice));
+    }
     return RM_OK;
 }
 
@@ -1177,12 +1228,12 @@ static void engine_free(rm_engine *e) {
     }
     if (e->xfer_stream) (void)hipStreamDestroy(e->xfer_stream);
     (void)hipFree(e->d_patch_obj);
-    (void)hipFree(e->d_pos);
-    (void)hipFree(e->d_col);
-    (void)hipFree(e->d_nrm);
-    (void)hipFree(e->d_emissive);
-    (void)hipFree(e->d_emissive_next);
-    (void)hipFree(e->d_ft);
+    (void)hipFree(e->d_sample_pos);
+    (void)hipFree(e->rad.col);
+    (void)hipFree(e->rad.nrm);
+    (void)hipFree(e->rad.emissive);
+    (void)hipFree(e->rad.emissive_next);
+    (void)hipFree(e->rad.ft);
     for (void *p : e->d_group_arrays) (void)hipFree(p);
 }
 
@@ -1423,6 +1474,12 @@ rm_engine *rm_engine_create(const rm_scene *scene, int width, int height, int ma
     e->scene = *scene;
     memcpy(e->camera, scene->camera, sizeof(float) * 3);
     if (engine_upload(e) != RM_OK) {
+        engine_free(e);
+        delete e;
+        return nullptr;
+    }
+    if (hipError_t err = static_scratch_of(device, &e->scratch); err != hipSuccess) {
+        fail(RM_ERR_HIP, std::string("hipGetSymbolAddress(scratch) failed: ") + hipGetErrorString(err));
         engine_free(e);
         delete e;
         return nullptr;
@@ -1771,39 +1828,68 @@ int rm_engine_probe_pack(rm_engine *e, int n, const float *linear, float exposur
 
 // ---- radiosity -------------------------------------------------------------
 
-int rm_engine_radiosity_begin(rm_engine *e) {
-    if (!e) return fail(RM_ERR_INVALID, "NULL engine");
-    HIP_TRY(hipSetDevice(e->device));
-    if (int rc_ = sync_view(e)) return rc_;
-    if (int rc_ = quiesce_frames_in_flight(e)) return rc_;  // the precompute rewrites the lightmaps they sample
-    const int NP = e->n_patches, M = e->M;
-    if (!e->d_pos) {
-        HIP_TRY(dev_alloc(&e->d_pos, (size_t)NP * 3));
-        HIP_TRY(dev_alloc(&e->d_col, (size_t)NP * 3));
-        HIP_TRY(dev_alloc(&e->d_nrm, (size_t)NP * 3));
-        HIP_TRY(dev_alloc(&e->d_emissive, (size_t)NP * 3));
-        HIP_TRY(dev_alloc(&e->d_emissive_next, (size_t)NP * 3));
-    }
-    e->rad_begun = true;
+}  // extern "C" (the steps below are shared by the allocating and the non-allocating entry points)
+
+// engine.rs:259-288: clouds and direct lighting of every patch into `b`.
+static int rad_begin_on(rm_engine *e, const RadBuffers &b) {
+    const int NP = e->n_patches;
     if (NP == 0) return RM_OK;
-    // engine.rs:269-273: the world position of every sample point
-    std::vector<float> pos((size_t)NP * 3);
-    for (int ci = 0; ci < e->n_lm; ci++) {
-        const HostObject &o = e->scene.objects[e->patch_obj[ci]];
-        for (int x = 0; x < M; x++)
-            for (int y = 0; y < M; y++)
-                if (!host_sample_pos(o, M, x, y, &pos[((size_t)(ci * M + x) * M + y) * 3]))
-                    return fail(RM_ERR_UNSUPPORTED, "object type has no lightmap parameterisation");
-    }
-    HIP_TRY(hipMemcpyAsync(e->d_pos, pos.data(), sizeof(float) * pos.size(), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));  // `pos` is pageable host memory
-    HIP_TRY(hipMemsetAsync(e->d_emissive_next, 0, sizeof(float) * 3 * NP, e->stream));
-    RadArgs a = e->rad_args();
+    if (!e->sample_pos_ok) return fail(RM_ERR_UNSUPPORTED, "object type has no lightmap parameterisation");
+    HIP_TRY(hipMemsetAsync(b.emissive_next, 0, sizeof(float) * 3 * NP, e->stream));
+    RadArgs a = e->rad_args(b);
     dim3 grid((NP + 63) / 64);
     hipLaunchKernelGGL(rad_cloud_kernel, grid, dim3(64), 0, e->stream, a);
     RM_LAUNCH(rad_direct_kernel, e, grid, dim3(64), a);
     HIP_TRY(hipGetLastError());
     return RM_OK;
+}
+
+static int rad_form_on(rm_engine *e, const RadBuffers &b, int p0, int p1) {
+    if (p0 == p1) return RM_OK;
+    const int NP = e->n_patches;
+    RadArgs a = e->rad_args(b);
+    // sources go into the grid's y dimension, 65535 at most per launch (RM_RAD_CHUNK: test hook)
+    int chunk = 65535;
+    if (const char *c = getenv("RM_RAD_CHUNK")) chunk = std::max(1, std::min(65535, atoi(c)));
+    for (int j0 = 0; j0 < NP; j0 += chunk) {
+        dim3 grid((p1 - p0 + 63) / 64, std::min(chunk, NP - j0));
+        RM_LAUNCH(rad_form_kernel, e, grid, dim3(64), a, p0, p1, j0);
+        HIP_TRY(hipGetLastError());
+    }
+    return RM_OK;
+}
+
+static int rad_bounce_on(rm_engine *e, const RadBuffers &b, int p0, int p1) {
+    if (p0 == p1) return RM_OK;
+    RadArgs a = e->rad_args(b);
+    dim3 grid((p1 - p0 + 63) / 64);
+    hipLaunchKernelGGL(rad_bounce_kernel, grid, dim3(256), 0, e->stream, a, p0, p1);
+    HIP_TRY(hipGetLastError());
+    return RM_OK;
+}
+
+static int rad_commit_on(rm_engine *e, const RadBuffers &b) {
+    if (e->n_patches)
+        HIP_TRY(hipMemcpyAsync(b.emissive, b.emissive_next, sizeof(float) * 3 * e->n_patches, hipMemcpyDeviceToDevice, e->stream));
+    return RM_OK;
+}
+
+extern "C" {
+
+int rm_engine_radiosity_begin(rm_engine *e) {
+    if (!e) return fail(RM_ERR_INVALID, "NULL engine");
+    HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
+    if (int rc_ = quiesce_frames_in_flight(e)) return rc_;  // the precompute rewrites the lightmaps they sample
+    const int NP = e->n_patches;
+    if (!e->rad.col) {
+        HIP_TRY(dev_alloc(&e->rad.col, (size_t)NP * 3));
+        HIP_TRY(dev_alloc(&e->rad.nrm, (size_t)NP * 3));
+        HIP_TRY(dev_alloc(&e->rad.emissive, (size_t)NP * 3));
+        HIP_TRY(dev_alloc(&e->rad.emissive_next, (size_t)NP * 3));
+    }
+    e->rad_begun = true;
+    return rad_begin_on(e, e->rad);
 }
 
 static int check_patch_range(rm_engine *e, int p0, int p1) {
@@ -1819,47 +1905,29 @@ int rm_engine_radiosity_form_factors(rm_engine *e, int p0, int p1) {
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_ = sync_view(e)) return rc_;
     const int NP = e->n_patches;
-    if (!e->d_ft) HIP_TRY(dev_alloc(&e->d_ft, (size_t)NP * NP));
-    if (p0 == p1) return RM_OK;
-    RadArgs a = e->rad_args();
-    // sources go into the grid's y dimension, 65535 at most per launch (RM_RAD_CHUNK: test hook)
-    int chunk = 65535;
-    if (const char *c = getenv("RM_RAD_CHUNK")) chunk = std::max(1, std::min(65535, atoi(c)));
-    for (int j0 = 0; j0 < NP; j0 += chunk) {
-        dim3 grid((p1 - p0 + 63) / 64, std::min(chunk, NP - j0));
-        RM_LAUNCH(rad_form_kernel, e, grid, dim3(64), a, p0, p1, j0);
-        HIP_TRY(hipGetLastError());
-    }
-    return RM_OK;
+    if (!e->rad.ft) HIP_TRY(dev_alloc(&e->rad.ft, (size_t)NP * NP));
+    return rad_form_on(e, e->rad, p0, p1);
 }
 
 int rm_engine_radiosity_bounce(rm_engine *e, int p0, int p1) {
     int rc = check_patch_range(e, p0, p1);
     if (rc) return rc;
-    if (!e->d_ft) return fail(RM_ERR_INVALID, "call rm_engine_radiosity_form_factors first");
-    if (p0 == p1) return RM_OK;
+    if (!e->rad.ft) return fail(RM_ERR_INVALID, "call rm_engine_radiosity_form_factors first");
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_ = sync_view(e)) return rc_;
-    RadArgs a = e->rad_args();
-    dim3 grid((p1 - p0 + 63) / 64);
-    hipLaunchKernelGGL(rad_bounce_kernel, grid, dim3(256), 0, e->stream, a, p0, p1);
-    HIP_TRY(hipGetLastError());
-    return RM_OK;
+    return rad_bounce_on(e, e->rad, p0, p1);
 }
 
 int rm_engine_radiosity_commit(rm_engine *e) {
     if (!e || !e->rad_begun) return fail(RM_ERR_INVALID, "radiosity not begun");
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_ = sync_view(e)) return rc_;
-    if (e->n_patches)
-        HIP_TRY(hipMemcpyAsync(e->d_emissive, e->d_emissive_next, sizeof(float) * 3 * e->n_patches,
-                               hipMemcpyDeviceToDevice, e->stream));
-    return RM_OK;
+    return rad_commit_on(e, e->rad);
 }
 
 int rm_engine_radiosity_buffers(rm_engine *e, void **d_next_emissive, void **d_lightmaps, int *n_patches) {
     if (!e || !e->rad_begun) return fail(RM_ERR_INVALID, "radiosity not begun");
-    if (d_next_emissive) *d_next_emissive = e->d_emissive_next;
+    if (d_next_emissive) *d_next_emissive = e->rad.emissive_next;
     if (d_lightmaps) *d_lightmaps = e->d_lightmaps;
     if (n_patches) *n_patches = e->n_patches;
     return RM_OK;
@@ -1877,6 +1945,44 @@ int rm_engine_compute_lightmaps(rm_engine *e, int bounces) {
         rc = rm_engine_radiosity_bounce(e, 0, e->n_patches);
         if (rc) return rc;
         rc = rm_engine_radiosity_commit(e);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RM_OK;
+}
+
+// Engine::compute_lightmaps without a single allocation: the clouds, the emissive maps and the
+// form-factor matrix live in the library's static scratch array (this device's copy of it) instead
+// of buffers the engine allocates on first use.  The kernels are the same and take the memory as
+// arguments, as they do for rm_engine_compute_lightmaps.
+int rm_engine_compute_lightmaps_static(rm_engine *e, int bounces) {
+    if (!e || bounces < 0) return fail(RM_ERR_INVALID, "bad argument");
+    const int NP = e->n_patches;
+    if (NP > RM_STATIC_MAX_PATCHES)
+        return fail(RM_ERR_LIMIT, "rm_engine_compute_lightmaps_static: " + std::to_string(NP) + " patches exceed the static scratch (" +
+                                      std::to_string(RM_STATIC_MAX_PATCHES) + " patches at most); use rm_engine_compute_lightmaps");
+    if (!e->scratch) return fail(RM_ERR_HIP, "the static scratch array has no address on this device");
+    HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
+    if (int rc_ = quiesce_frames_in_flight(e)) return rc_;
+    // the scratch array, cut up for NP patches: four [NP][3] arrays, then FT [NP][NP] on a 256-byte boundary
+    const size_t cloud = ((size_t)NP * 3 + 63) & ~(size_t)63;
+    RadBuffers b;
+    b.col = e->scratch;
+    b.nrm = b.col + cloud;
+    b.emissive = b.nrm + cloud;
+    b.emissive_next = b.emissive + cloud;
+    b.ft = b.emissive_next + cloud;
+    int rc = rad_begin_on(e, b);  // writes every cloud entry and zeroes emissive_next; FT is written in full below
+    if (rc) return rc;
+    if (bounces > 0) {
+        rc = rad_form_on(e, b, 0, NP);
+        if (rc) return rc;
+    }
+    for (int k = 0; k < bounces; k++) {
+        rc = rad_bounce_on(e, b, 0, NP);
+        if (rc) return rc;
+        rc = rad_commit_on(e, b);
         if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(e->stream));

@@ -109,6 +109,11 @@ class Engine:
     def compute_lightmaps(self, bounces=4):
         _lib.check(self.lib.rm_engine_compute_lightmaps(self.handle, bounces), "rm_engine_compute_lightmaps")
 
+    def compute_lightmaps_static(self, bounces=4):
+        """compute_lightmaps without any allocation: work buffers in the library's static device array
+        (at most _lib.RM_STATIC_MAX_PATCHES patches; calls that overlap on one GPU race)."""
+        _lib.check(self.lib.rm_engine_compute_lightmaps_static(self.handle, bounces), "rm_engine_compute_lightmaps_static")
+
     def radiosity_begin(self):
         _lib.check(self.lib.rm_engine_radiosity_begin(self.handle), "rm_engine_radiosity_begin")
 
