@@ -274,6 +274,81 @@ int rm_engine_reset_stats(rm_engine *engine);
 /* Block until everything enqueued on the engine's stream has finished. */
 int rm_engine_synchronize(rm_engine *engine);
 
+/* ---- several GPUs ----------------------------------------------------------
+ *
+ * The reference spreads a frame over CPU threads by image rows (rayon, engine.rs:93) inside the one
+ * Engine::render call its main loop makes per frame (main.rs:141-145); it has no second device to
+ * talk to.  Here the rows of a frame are spread over GPUs as interleaved strips of RM_STRIP_ROWS rows
+ * (GPU r of n renders strips r, r+n, ...: even load wherever the expensive pixels are), behind two
+ * forms of the same per-frame call. */
+
+/* Form 1 - one rank per GPU, each in a process (or thread) of its own, frames left in HBM on every
+ * rank.  The strips travel as 3 bytes per pixel through one all-gather per frame: RCCL over xGMI
+ * (librccl.so is looked up at run time; RM_ERR_UNSUPPORTED if there is none), or an all-gather the
+ * host supplies (MPI, a test double).  Replaces the rayon fan-out of engine.rs:93,116. */
+typedef struct rm_group rm_group;
+#define RM_GROUP_ID_BYTES 128
+#define RM_GROUP_MAX_FRAMES_IN_FLIGHT 4
+
+/* An RCCL unique id (ncclGetUniqueId): one rank makes it, the host hands its 128 bytes to the others. */
+int rm_group_unique_id(uint8_t id[RM_GROUP_ID_BYTES]);
+
+/* Rank `rank` of `world` over `engine` (same scene, size and map_size on every rank); collective:
+ * every rank calls it with the same id.  `frames_in_flight` (1..4) frames overlap, each on a stream
+ * of its own.  The engine must outlive the group. */
+rm_group *rm_group_create(rm_engine *engine, const uint8_t id[RM_GROUP_ID_BYTES], int rank, int world, int frames_in_flight);
+
+/* The same with the host's own exchange: all_gather must leave, in `d_recv` on every rank, the
+ * `bytes_per_rank` bytes at `d_send` of rank 0, 1, ... one after the other, ordered on `hip_stream`
+ * (or complete on return); non-zero return = failure. */
+typedef int (*rm_allgather_fn)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank, void *hip_stream);
+rm_group *rm_group_create_custom(rm_engine *engine, int rank, int world, int frames_in_flight, rm_allgather_fn all_gather, void *user);
+void rm_group_destroy(rm_group *group);
+int rm_group_info(const rm_group *group, int *rank, int *world, int *strips_per_rank, int *bytes_per_pixel_exchanged);
+
+/* Engine::compute_lightmaps (engine.rs:246-326) with the receiver patches split over the ranks: each
+ * rank computes the form factors of its patches once and per bounce its slice of the next emissive
+ * map; one all-gather per bounce (a bounce reads only the previous one's values, engine.rs:299-325)
+ * and one of the lightmaps at the end.  Collective; returns when this rank holds all lightmaps. */
+int rm_group_compute_lightmaps(rm_group *group, int bounces);
+
+/* Engine::render (engine.rs:38-127) for the group, one call per rank and frame: the input block is
+ * applied (every rank passes the same values and so keeps the same camera), this rank's strips are
+ * rendered, all-gathered and put in row order, and with fxaa != 0 the gathered frame is filtered
+ * (fxaa.txt, as rm_engine_fxaa_device) - the whole frame, B,G,R,0 rows of width*4 bytes, lands in
+ * `d_bgra_frame` (device memory) on every rank.  Asynchronous: the call only enqueues; frame f and
+ * frame f + frames_in_flight share a stream and buffers, all others overlap.  Collective: every rank
+ * issues the same frames in the same order. */
+int rm_group_frame(rm_group *group, void *d_bgra_frame, int fxaa, int32_t mouse_x, int32_t mouse_y, const float rel_move[3],
+                   int32_t scroll);
+/* Blocks until every frame enqueued so far has landed in its buffer. */
+int rm_group_wait(rm_group *group);
+
+/* Measurement aid: with on != 0 every frame's render launch is bracketed by events on its stream;
+ * rm_group_render_time waits for the frames and returns the mean over the (up to 256) last ones. */
+int rm_group_set_timing(rm_group *group, int on);
+int rm_group_render_time(rm_group *group, double *mean_ms, int *frames);
+
+/* Form 2 - one process, `n_devices` GPUs, the frame wanted in host memory: what a host shaped like
+ * main.rs holds (Engine{..} at main.rs:64-71, compute_lightmaps at :73, render into the locked
+ * texture at :141-145).  One engine per listed device (a device may be listed more than once), one
+ * host thread per engine inside the library; every GPU copies its strips over its own PCIe link
+ * straight into the caller's frame, so no data moves between GPUs for a frame. */
+typedef struct rm_multi rm_multi;
+rm_multi *rm_multi_create(const rm_scene *scene, int width, int height, int map_size, const int *devices, int n_devices);
+void rm_multi_destroy(rm_multi *multi);
+int rm_multi_device_count(const rm_multi *multi);
+/* The engine on the index-th listed device, e.g. for rm_engine_get_lightmap or the rm_engine_set_*
+ * switches (set them on every engine alike, while no call on `multi` is running). */
+rm_engine *rm_multi_engine(rm_multi *multi, int index);
+/* Engine::compute_lightmaps, receiver patches split over the GPUs, slices exchanged through
+ * page-locked host memory once per bounce. */
+int rm_multi_compute_lightmaps(rm_multi *multi, int bounces);
+/* Engine::render: as rm_engine_render (same arguments, same bytes in `bgra`), GPU i of n rendering
+ * strips i, i+n, ... */
+int rm_multi_render(rm_multi *multi, uint8_t *bgra, size_t pitch_bytes, int32_t mouse_x, int32_t mouse_y, const float rel_move[3],
+                    int32_t scroll);
+
 #ifdef __cplusplus
 }
 #endif

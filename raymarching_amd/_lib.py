@@ -4,13 +4,14 @@ There is no fallback: if the HIP library is missing, loading raises.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
+from ctypes import CFUNCTYPE, POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librm_hip.so")
 
 RM_STAT_COUNT = 8
 RM_STATIC_MAX_PATCHES = 1024
+RM_GROUP_ID_BYTES = 128
 STAT_NAMES = ("depth_cap_hits", "step_cap_hits", "lightmap_oob", "texture_oob")
 
 
@@ -19,6 +20,8 @@ class Material(ctypes.Structure):
 
 
 _F3 = POINTER(c_float)
+# rm_allgather_fn: (user, d_send, d_recv, bytes_per_rank, hip_stream) -> status
+ALLGATHER_FN = CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p)
 
 # name -> (restype, argtypes); mirrors include/rm.h one to one
 SIGNATURES = {
@@ -72,6 +75,22 @@ SIGNATURES = {
     "rm_engine_get_stats": (c_int, [c_void_p, POINTER(c_uint64)]),
     "rm_engine_reset_stats": (c_int, [c_void_p]),
     "rm_engine_synchronize": (c_int, [c_void_p]),
+    "rm_group_unique_id": (c_int, [POINTER(c_uint8)]),
+    "rm_group_create": (c_void_p, [c_void_p, POINTER(c_uint8), c_int, c_int, c_int]),
+    "rm_group_create_custom": (c_void_p, [c_void_p, c_int, c_int, c_int, ALLGATHER_FN, c_void_p]),
+    "rm_group_destroy": (None, [c_void_p]),
+    "rm_group_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "rm_group_compute_lightmaps": (c_int, [c_void_p, c_int]),
+    "rm_group_frame": (c_int, [c_void_p, c_void_p, c_int, c_int32, c_int32, _F3, c_int32]),
+    "rm_group_wait": (c_int, [c_void_p]),
+    "rm_group_set_timing": (c_int, [c_void_p, c_int]),
+    "rm_group_render_time": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int)]),
+    "rm_multi_create": (c_void_p, [c_void_p, c_int, c_int, c_int, POINTER(c_int), c_int]),
+    "rm_multi_destroy": (None, [c_void_p]),
+    "rm_multi_device_count": (c_int, [c_void_p]),
+    "rm_multi_engine": (c_void_p, [c_void_p, c_int]),
+    "rm_multi_compute_lightmaps": (c_int, [c_void_p, c_int]),
+    "rm_multi_render": (c_int, [c_void_p, POINTER(c_uint8), c_size_t, c_int32, c_int32, _F3, c_int32]),
 }
 
 _lib = None

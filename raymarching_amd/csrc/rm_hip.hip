@@ -734,6 +734,7 @@ struct rm_engine {
     float *d_sample_pos = nullptr;  // [n_patches][3]: the point cloud of engine.rs:269-273, uploaded at creation
     bool sample_pos_ok = false;     // false: some lightmapped type has no sample positions
     float *scratch = nullptr;  // this device's copy of the library's static scratch array
+    std::vector<hipStream_t> attached_streams;  // streams of rm_group frames in flight on this engine
 
     SceneView view() const {
         SceneView sv;
@@ -1257,6 +1258,7 @@ static void engine_free(rm_engine *e) {
 static int quiesce_frames_in_flight(rm_engine *e) {
     for (int i = 0; i < RM_FRAMES_IN_FLIGHT; i++)
         if (e->async_pending[i] && e->slot_stream[i]) HIP_TRY(hipStreamSynchronize(e->slot_stream[i]));
+    for (hipStream_t s : e->attached_streams) HIP_TRY(hipStreamSynchronize(s));
     return RM_OK;
 }
 
@@ -2076,3 +2078,5 @@ int rm_engine_synchronize(rm_engine *e) {
 }
 
 }  // extern "C"
+
+#include "rm_group.hpp"
