@@ -3,9 +3,10 @@
 
 One "step" is one frame: every primary ray of the 4K image through march, shading
 (texture, lightmap, Phong, soft shadow, reflections), tone map and pack, written
-as B,G,R,0 bytes into HBM.  With N > 1 the frame is split into N row bands, one
-per rank, and the bands are all-gathered over RCCL so that every rank ends up with
-the whole frame (strong scaling: the work per frame is fixed).
+as B,G,R,0 bytes into HBM.  With N > 1 the frame is split into interleaved 8-row
+strips, rank r rendering strips r, r+N, ..., and one all-gather per frame (RCCL,
+issued inside the library by rm_group_frame) leaves the whole frame on every rank
+(strong scaling: the work per frame is fixed).
 
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -38,8 +39,7 @@ def parse_args():
     ap.add_argument("--refraction", action="store_true", help="the refraction block the reference carries commented out (engine.rs:196-228)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the CPU baseline leg")
-    ap.add_argument("--no-pack", action="store_true", help="exchange 4 bytes per pixel instead of 3 (the fourth byte of a pixel is always 0)")
-    ap.add_argument("--no-overlap", action="store_true", help="wait for each frame's all-gather before the next render")
+    ap.add_argument("--no-overlap", action="store_true", help="wait for each frame of the group before the next is issued")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="1 = frames one after the other; n = consecutive frames on n streams, so that the long-running "
                          "tiles at the end of one frame overlap the start of the next ones (default: 1 on one GPU, 3 on several)")
@@ -107,20 +107,97 @@ def cpu_baseline(scene, lightmaps, width, height, budget_s, ssaa=False, refracti
     }, frame
 
 
+def radiosity_flops(map_size, bounces=4):
+    """Algorithmic flops of Engine::compute_lightmaps as the reference runs it (every bounce marches
+    every patch pair again, radiosity.rs:119-153): from the oracle's event counts at MAP_SIZE 8;
+    other sizes are scaled by the number of patch pairs (M^4), which is exact for the per-pair
+    arithmetic and an estimate for the march steps."""
+    from raymarching_amd.flops import frame_flops
+
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "counters.json")) as f:
+            c = json.load(f)["radiosity_map8_bounces4"]
+    except (OSError, KeyError):
+        return None
+    pairs8 = 512 * 448
+    per_pair = 40  # radiosity.rs:126-152 besides the march: difference, length, division, two dots, product, max, division, min, 3 multiply-adds
+    at8 = frame_flops(c) + per_pair * pairs8 * 4
+    return int(at8 * (map_size / 8.0) ** 4 * bounces / 4)
+
+
+def radiosity_cpu_baseline(scene, budget_s):
+    """The CPU oracle's compute_lightmaps (single thread, as the reference's) at MAP_SIZE 8, repeated
+    until about `budget_s` seconds are spent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+
+    e = oracle.OracleEngine(scene)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        e.compute_lightmaps(4)
+        times.append(time.perf_counter() - t0)
+    e.close()
+    times.sort()
+    median = times[len(times) // 2]
+    marches = 512 * 448 * 4 + 512  # the reference marches every pair again in every bounce, plus direct lighting
+    return {
+        "value": marches / median / 1e6,
+        "unit": "Mmarches/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{len(times)} runs of compute_lightmaps at MAP_SIZE 8 (512 patches, {marches} occlusion marches each, 4 bounces), "
+        f"median {median:.2f} s, single thread as the reference (main.rs:73 runs it before the thread pool exists)",
+    }
+
+
 def radiosity_workload(args, world, rank, local_rank, backend):
     """One step = Engine::compute_lightmaps (engine.rs:246-326): clouds, direct lighting, the
     form-factor matrix of all patch pairs, 4 bounces; receiver patches sharded over the ranks with
-    one all-gather per bounce."""
+    one all-gather per bounce (inside the library, rm_group_compute_lightmaps)."""
     import torch
     import torch.distributed as dist
 
     from raymarching_amd import Engine, default_scene
-    from raymarching_amd.dist import compute_lightmaps_sharded
 
     M = args.map_size
-    eng = Engine(default_scene(), 64, 64, map_size=M, device=local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    scene = default_scene()
+    eng = Engine(scene, 64, 64, map_size=M, device=local_rank)
+    gathering = world > 1 or os.environ.get("RM_BENCH_GATHER_ALONE") == "1"
+    group = None
+    if gathering:
+        from raymarching_amd.group import Group, unique_id
+
+        ids = [unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        group = Group(eng, rank, world, ids[0], frames_in_flight=1)
     steps, warmup = min(args.steps, 20), min(args.warmup, 3)
+    n = 8 * M * M
+    phase_ms = {"form_factors": 0.0, "bounces": 0.0}
+
+    def step(timed):
+        if gathering:
+            group.compute_lightmaps(4)
+            return
+        if not timed:
+            eng.compute_lightmaps(4)
+            return
+        # the same calls rm_engine_compute_lightmaps makes, with events between the phases (null stream)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        eng.radiosity_begin()
+        ev[0].record()
+        eng.radiosity_form_factors(0, n)
+        ev[1].record()
+        for _ in range(4):
+            eng.radiosity_bounce(0, n)
+            eng.radiosity_commit()
+        ev[2].record()
+        eng.synchronize()
+        torch.cuda.synchronize()
+        phase_ms["form_factors"] += ev[0].elapsed_time(ev[1])
+        phase_ms["bounces"] += ev[1].elapsed_time(ev[2])
 
     def fence():
         torch.cuda.synchronize()
@@ -129,21 +206,20 @@ def radiosity_workload(args, world, rank, local_rank, backend):
         torch.cuda.synchronize()
 
     for _ in range(warmup):
-        compute_lightmaps_sharded(eng, 4)
+        step(False)
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        compute_lightmaps_sharded(eng, 4)
+        step(True)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        n = 8 * M * M
         pairs = n * (n - M * M)
-        print(json.dumps({
+        result = {
             "metric": "radiosity occlusion marches per second (Engine::compute_lightmaps, 4 bounces)",
             "value": pairs / (elapsed / steps) / 1e6,
             "unit": "Mmarches/s",
@@ -157,8 +233,36 @@ def radiosity_workload(args, world, rank, local_rank, backend):
             "dtype": "f32",
             "data": "synthetic: the reference's default scene",
             "config": {"workload": f"compute_lightmaps, default scene, MAP_SIZE={M}, 4 bounces", "map_size": M,
-                       "patches": n, "patch_pairs": pairs, "sharding": "receiver patches, all-gather per bounce"},
-        }), flush=True)
+                       "patches": n, "patch_pairs": pairs, "sharding": "receiver patches, all-gather per bounce" if gathering else "none",
+                       "note": "value counts each patch pair once (the form factors are computed once); the reference marches every pair again in every bounce"},
+        }
+        if not gathering:
+            form_ms = phase_ms["form_factors"] / steps
+            bounce_ms = phase_ms["bounces"] / steps / 4
+            flops = radiosity_flops(M)
+            hbm = {"bound": "hbm", "achieved": 4.0 * n * n / (bounce_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                   "traffic": None, "kernel": "rad_bounce_kernel", "kernel_ms": bounce_ms,
+                   "algorithmic_bytes_per_launch": 4 * n * n,
+                   "note": "one bounce reads the [patches][patches] f32 form-factor matrix once: 4 bytes per (receiver, source) term"}
+            hbm["frac"] = hbm["achieved"] / hbm["peak"]
+            valu = None
+            if flops is not None:
+                # the reference's flops are those of marching every pair in each of the 4 bounces; rad_form_kernel does that work once
+                achieved = flops / (form_ms * 1e-3) / 1e12
+                valu = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                        "frac_of_no_fma_peak": achieved / PEAK_FP32_NO_FMA_TFLOPS, "traffic": None, "kernel": "rad_form_kernel",
+                        "kernel_ms": form_ms, "algorithmic_flops_per_launch": flops,
+                        "note": "algorithmic flops of the reference's 4 x (patch pairs) occlusion marches, counted by the oracle at MAP_SIZE 8"
+                        + ("" if M == 8 else " and scaled by the patch-pair count (estimate)") + "; the kernel marches each pair once"}
+            dominant_is_form = form_ms >= 4 * bounce_ms
+            result["roofline"] = valu if (dominant_is_form and valu) else hbm
+            result["roofline_other_kernel"] = hbm if (dominant_is_form and valu) else valu
+            result["phase_ms"] = {"form_factors": form_ms, "one_bounce": bounce_ms}
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"] = radiosity_cpu_baseline(scene, args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    if group is not None:
+        group.close()
     eng.close()
     if world > 1:
         dist.barrier()
@@ -188,22 +292,16 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     # RM_BENCH_GATHER_ALONE=1 (rehearsal, not used by the driver): one rank forms an RCCL group by itself
-    # and runs the several-GPU path - strips, asynchronous all-gather, re-ordering, frames in flight -
-    # on the real backend; the exchange then is a copy.
+    # and runs the several-GPU path - strips, all-gather, re-ordering, frames in flight - on the real
+    # backend; the exchange then is a copy.
     gathering = world > 1 or os.environ.get("RM_BENCH_GATHER_ALONE") == "1"
-    if gathering and world == 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-    if gathering:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+    if world > 1:
+        # torch.distributed only carries the 128-byte group id, the barriers around the timed region and
+        # the maximum over the ranks' times: gloo does.  The frames and lightmaps travel inside the library.
+        dist.init_process_group("gloo")
 
     from raymarching_amd import Engine, default_scene
-    from raymarching_amd.dist import STRIP_ROWS, band_rows, deinterleave_strips, strip_plan
+    from raymarching_amd.dist import STRIP_ROWS
     from raymarching_amd.flops import frame_flops
 
     if args.workload == "radiosity":
@@ -240,145 +338,97 @@ def main():
     if args.refraction:
         eng.set_refraction(True)
 
-    # Sharding: without FXAA rank r renders the 8-row strips r, r+N, r+2N, ... (even load however
-    # the cost is spread over the image); with FXAA it renders one contiguous band plus the few rows
-    # the filter reads around it.  Either way every rank contributes the same number of rows.
-    interleaved = gathering and not args.fxaa
-    if interleaved:
-        first_strip, strip_stride, strips_per_rank = strip_plan(H, rank, world)
-        band_h = strips_per_rank * STRIP_ROWS
-        my_rows = sum(min(STRIP_ROWS, H - (first_strip + k * strip_stride) * STRIP_ROWS)
-                      for k in range(strips_per_rank) if (first_strip + k * strip_stride) * STRIP_ROWS < H)
-        r0, r1 = 0, my_rows  # only the row count is used below
-    else:
-        band_h = (H + world - 1) // world
-        r0, r1 = band_rows(H, rank, world)
-    # A rank's share of a frame is bounded by its few slowest tiles, not by its size, so several
-    # frames are kept in flight: measured on one GPU, an eighth of the 3840x2160 frame takes 0.132 ms
-    # alone, 0.066 ms per frame with two in flight and 0.045 ms with three (0.039 would be an eighth
-    # of the whole frame's time); a fourth stream gains nothing.
+    # Several GPUs: rank r renders the 8-row strips r, r+N, r+2N, ... (even load however the cost is
+    # spread over the image) and the library does the rest of a frame in one C call per rank
+    # (rm_group_frame): strips -> 3 bytes per pixel -> all-gather on the frame's own stream (RCCL) ->
+    # rows in order -> FXAA on the gathered frame.  A rank's share of a frame is bounded by its few
+    # slowest tiles, not by its size, so three frames are kept in flight (measured on one GPU: an
+    # eighth of the 3840x2160 frame takes 0.132 ms alone, 0.045 ms per frame with three in flight).
     in_flight = args.frames_in_flight or (3 if gathering else 1)
     if args.no_overlap:
         in_flight = 1
-    n_buf = max(in_flight, 2)  # one set of buffers per frame in flight (two at least: gather f beside render f+1)
-    # Rows cross xGMI as 3 bytes per pixel (byte 3 of a rendered pixel is 0, engine.rs:116-126): a rank
-    # packs its rows before the all-gather and one kernel unpacks and orders the gathered rows.
-    packing = gathering and W % 4 == 0 and not args.no_pack
-    wire = 3 if packing else 4
-    bands = [torch.zeros((band_h, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
-    wire_bands = [torch.zeros((band_h, W, 3), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if packing else bands
-    frames = [torch.zeros((world * band_h, W, wire), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
-    final = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if interleaved or packing else None
-    fx_srcs = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if args.fxaa else None
+    n_buf = max(in_flight, 2)
+    group = None
+    if gathering:
+        from raymarching_amd.group import Group, unique_id
+
+        if backend == "nccl":
+            # the 128-byte id is the only thing the ranks exchange outside the library
+            ids = [unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            group = Group(eng, rank, world, ids[0], frames_in_flight=in_flight)
+        else:
+            # rehearsal on one GPU: RCCL refuses two ranks on one device, so the all-gather goes
+            # through host memory and gloo; everything else is the path above
+            def host_all_gather(d_send, d_recv, nbytes, hip_stream):
+                from raymarching_amd.dist import _alias_u8
+
+                torch.cuda.synchronize()
+                mine = _alias_u8(d_send, nbytes, local_rank).cpu()
+                everyone = torch.empty(nbytes * world, dtype=torch.uint8)
+                dist.all_gather_into_tensor(everyone, mine)
+                _alias_u8(d_recv, nbytes * world, local_rank).copy_(everyone)
+                torch.cuda.synchronize()
+                return 0
+
+            group = Group(eng, rank, world, frames_in_flight=in_flight, all_gather=host_all_gather)
+        if args.workload != "stress":
+            group.compute_lightmaps(4)  # the same precompute, patch-sharded (a rehearsal of that exchange too)
+        info = group.info()
+        strips_per_rank, wire = info["strips_per_rank"], info["bytes_per_pixel_exchanged"]
+        my_rows = sum(min(STRIP_ROWS, H - (rank + k * world) * STRIP_ROWS) for k in range(strips_per_rank) if (rank + k * world) * STRIP_ROWS < H)
+        r0, r1 = 0, my_rows  # only the row count is used below
+    else:
+        r0, r1 = 0, H
+        wire = None
+    final = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
+    fx_srcs = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if args.fxaa and not gathering else None
 
     kernel_events = []
-    # frame s is rendered, gathered and put in order on streams[s % in_flight]
+    # one GPU: frame s is rendered (and filtered) on streams[s % in_flight]
     streams = [stream] + [torch.cuda.Stream() for _ in range(in_flight - 1)]
 
-    def render_band(buf, timed):
-        fx_src = fx_srcs[next(i for i, b in enumerate(bands) if b is buf)] if args.fxaa else None  # one per frame in flight
-        stream = torch.cuda.current_stream()
-        eng.set_stream(stream.cuda_stream)
+    def render_whole(b, timed):
+        st = torch.cuda.current_stream()
+        eng.set_stream(st.cuda_stream)
         if timed:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev1 = torch.cuda.Event(enable_timing=True)
-            ev0.record(stream)
-        if args.fxaa:
-            # band plus the rows FXAA reads around it (one above, four below)
-            h0, h1 = max(r0 - 1, 0), min(r1 + 4, H)
-            eng.render_rows_device(fx_src[h0].data_ptr(), h0, h1)
-            if timed:
-                ev1.record(stream)
-            # the band buffer stands in for rows r0.. of a frame-shaped destination
-            eng.fxaa_device(fx_src.data_ptr(), buf.data_ptr() - r0 * W * 4, r0, r1)
-        elif interleaved:
-            eng.render_strips_device(buf.data_ptr(), first_strip, strip_stride, strips_per_rank)
-            if timed:
-                ev1.record(stream)
-        else:
-            eng.render_rows_device(buf.data_ptr(), r0, r1)
-            if timed:
-                ev1.record(stream)
+            ev0.record(st)
+        dst = fx_srcs[b] if args.fxaa else final[b]
+        eng.render_rows_device(dst.data_ptr(), 0, H)
         if timed:
+            ev1.record(st)
             kernel_events.append((ev0, ev1))
-        if packing:
-            eng.pack_bgr_device(buf.data_ptr(), wire_bands[next(i for i, b in enumerate(bands) if b is buf)].data_ptr(), band_h * W)
-
-    class _HostStagedGather:
-        """gloo rehearsal only: all-gather through host memory, same interface as an async work handle."""
-
-        def __init__(self, out, inp):
-            cpu_in = inp.cpu()
-            cpu_out = torch.empty(out.numel(), dtype=torch.uint8)
-            dist.all_gather_into_tensor(cpu_out, cpu_in)
-            out.copy_(cpu_out)
-
-        def wait(self):
-            pass
-
-    def start_gather(out, inp):
-        if backend == "nccl":
-            return dist.all_gather_into_tensor(out, inp, async_op=True)
-        return _HostStagedGather(out, inp)
-
-    def finish(pending):
-        """Frame f is complete on this rank once its gather has landed (and, for strips, been put in row order)."""
-        work, b = pending
-        work.wait()
-        if packing:
-            eng.set_stream(torch.cuda.current_stream().cuda_stream)
-            if interleaved:
-                eng.unpack_bgr_strips_device(frames[b].data_ptr(), final[b].data_ptr(), world, strips_per_rank)
-            else:  # contiguous bands are in row order already
-                eng.unpack_bgr_strips_device(frames[b].data_ptr(), final[b].data_ptr(), 1, (H + STRIP_ROWS - 1) // STRIP_ROWS)
-        elif interleaved:
-            final[b].copy_(deinterleave_strips(frames[b], world, strips_per_rank, W, H))
+        if args.fxaa:
+            eng.fxaa_device(fx_srcs[b].data_ptr(), final[b].data_ptr(), 0, H)
 
     def run(steps, timed):
-        if in_flight == 1:
-            pending = None
+        if gathering:
+            group.set_timing(timed)
             for s in range(steps):
-                b = s & 1
-                render_band(bands[b], timed)
-                if gathering:
-                    if pending is not None:
-                        finish(pending)
-                    pending = (start_gather(frames[b].view(-1), wire_bands[b].view(-1)), b)
-                    if args.no_overlap:
-                        finish(pending)
-                        pending = None
-            if pending is not None:
-                finish(pending)
+                group.frame(final[s % n_buf].data_ptr(), args.fxaa)
+                if args.no_overlap:
+                    group.wait()
+            group.wait()
             return
-        # Several frames in flight: frame s lives on streams[s % in_flight] from its render to the
-        # re-ordering of its gathered strips, so the renders of the next frames run beside the tail of
-        # frame s.  Buffer set b is reused by frame s + in_flight on the same stream, after frame s has
-        # been finished there.
-        pending = [None] * in_flight
+        if in_flight == 1:
+            for s in range(steps):
+                render_whole(s & 1, timed)
+            return
         for st in streams:
             st.wait_stream(stream)
         for s in range(steps):
-            b = s % in_flight
-            with torch.cuda.stream(streams[b]):
-                if pending[b] is not None:
-                    finish(pending[b])
-                    pending[b] = None
-                render_band(bands[b], timed)
-                if gathering:
-                    pending[b] = (start_gather(frames[b].view(-1), wire_bands[b].view(-1)), b)
-        for s in range(max(steps - in_flight, 0), steps):  # oldest frame first
-            b = s % in_flight
-            if pending[b] is not None:
-                with torch.cuda.stream(streams[b]):
-                    finish(pending[b])
-                pending[b] = None
+            with torch.cuda.stream(streams[s % in_flight]):
+                render_whole(s % in_flight, timed)
         for st in streams[1:]:
             stream.wait_stream(st)
         eng.set_stream(stream.cuda_stream)
 
     def fence():
         torch.cuda.synchronize()
-        if gathering:
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -389,15 +439,18 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
+    if gathering:
+        kernel_ms, _ = group.render_time()  # events around the render launch on each frame's own stream
+    else:
+        kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
     stats = eng.stats()
 
     result = None
-    last_buf = (args.steps - 1) % in_flight if in_flight > 1 else (args.steps - 1) & 1  # where the last frame landed
+    last_buf = (args.steps - 1) % n_buf if gathering or in_flight > 1 else (args.steps - 1) & 1  # where the last frame landed
     if rank == 0:
         rays = W * H * (4 if args.ssaa else 1)
         ms_per_step = elapsed / args.steps * 1e3
@@ -441,7 +494,9 @@ def main():
                 "width": W,
                 "height": H,
                 "bands": world,
-                "sharding": "interleaved 8-row strips" if interleaved else "contiguous row bands",
+                "sharding": "interleaved 8-row strips" if gathering else "none",
+                "exchange": ("one all-gather per frame inside the library (rm_group_frame), " + ("RCCL" if backend == "nccl" else "gloo through host memory (rehearsal)")) if gathering else None,
+                "fxaa_after_gather": bool(args.fxaa and gathering),
                 "fxaa": bool(args.fxaa),
                 "ssaa": 4 if args.ssaa else 1,
                 "refraction": bool(args.refraction),
@@ -455,7 +510,7 @@ def main():
         }
         if gathering:
             # the gathered frame against the same frame rendered (and filtered) whole on this GPU, bit for bit
-            gathered = (final if final is not None else frames)[last_buf][:H]
+            gathered = final[last_buf]
             local = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
             eng.render_rows_device(local.data_ptr(), 0, H)
             if args.fxaa:
@@ -470,12 +525,7 @@ def main():
             result["cpu_baseline"] = base
             if not args.fxaa:
                 # the same frame from the GPU: a parity check at the benchmarked size
-                full = (final if final is not None else frames)[last_buf] if gathering else None
-                if full is None:
-                    full = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
-                    eng.render_rows_device(full.data_ptr(), 0, H)
-                    torch.cuda.synchronize()
-                gpu_rows = full[:H].cpu().numpy()
+                gpu_rows = final[last_buf].cpu().numpy()
                 diff = np.abs(gpu_rows.astype(np.int16) - cpu_rows.astype(np.int16))
                 result["parity_vs_cpu_frame"] = {
                     "max_abs_diff": int(diff.max()),
@@ -483,8 +533,10 @@ def main():
                 }
         print(json.dumps(result), flush=True)
 
+    if group is not None:
+        group.close()
     eng.close()
-    if gathering:
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

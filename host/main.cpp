@@ -3,10 +3,14 @@
 // prints "Elapsed" per frame (main.rs:140-149).  Instead of an SDL window the
 // last frame is written as a 32-bit BMP.
 //
-//   rm_headless [--frames N] [--width W] [--height H] [--out frame.bmp] [--texture path]
+//   rm_headless [--frames N] [--width W] [--height H] [--out frame.bmp] [--texture path] [--devices 0,1,2,...]
+//
+// With --devices the frame and the lightmap patches are spread over the listed GPUs (one process,
+// one engine per GPU; a GPU may be listed more than once).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -52,6 +56,7 @@ static void write_bmp32(const std::string &path, const std::vector<uint8_t> &bgr
 int main(int argc, char **argv) {
     int frames = 5, width = 800, height = 600;  // engine.rs:9-10
     std::string out = "frame.bmp", texture = "assets/textures/Floor128.bmp";
+    std::vector<int> devices;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i];
         if (k == "--frames") frames = atoi(argv[i + 1]);
@@ -59,11 +64,21 @@ int main(int argc, char **argv) {
         else if (k == "--height") height = atoi(argv[i + 1]);
         else if (k == "--out") out = argv[i + 1];
         else if (k == "--texture") texture = argv[i + 1];
+        else if (k == "--devices") {
+            for (const char *p = argv[i + 1]; *p;) {
+                devices.push_back(atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
+        }
     }
     printf("Hello, world!\n");  // main.rs:33
     try {
-        Engine engine(construct_objects(texture), Vec3{0.0f, 0.5f, -3.5f}, PointLight{Vec3{2.0f, -1.0f, 1.5f}, 3.5f}, width,
-                      height);
+        const Vec3 camera{0.0f, 0.5f, -3.5f};
+        const PointLight light{Vec3{2.0f, -1.0f, 1.5f}, 3.5f};
+        std::unique_ptr<Engine> owned(devices.empty() ? new Engine(construct_objects(texture), camera, light, width, height)
+                                                      : new Engine(construct_objects(texture), camera, light, width, height, 8, devices));
+        Engine &engine = *owned;
         engine.compute_lightmaps();
         std::vector<uint8_t> buffer((size_t)width * height * 4);
         int32_t mouse_x = 0, mouse_y = 0, scroll = 0;  // main.rs:78-80
@@ -75,7 +90,8 @@ int main(int argc, char **argv) {
             printf("Elapsed: %.2fms\n", ms);
         }
         write_bmp32(out, buffer, width, height);
-        printf("{\"width\": %d, \"height\": %d, \"frames\": %d, \"image\": \"%s\"}\n", width, height, frames, out.c_str());
+        printf("{\"width\": %d, \"height\": %d, \"frames\": %d, \"gpus\": %d, \"image\": \"%s\"}\n", width, height, frames,
+               devices.empty() ? 1 : (int)devices.size(), out.c_str());
     } catch (const std::exception &e) {
         fprintf(stderr, "rm_headless: %s\n", e.what());
         return 1;

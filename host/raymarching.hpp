@@ -139,6 +139,72 @@ class Engine {
     Engine(const std::vector<EngineObject> &objects, Vec3 camera_position, PointLight light, int width, int height,
            int map_size = 8, int device = 0)
         : width_(width), height_(height) {
+        rm_scene *scene = build_scene(objects, camera_position, light);
+        handle_ = rm_engine_create(scene, width, height, map_size, device);
+        rm_scene_destroy(scene);
+        if (!handle_) throw std::runtime_error(std::string("rm_engine_create: ") + rm_last_error());
+        engines_.push_back(handle_);
+    }
+    // The same engine over several GPUs of this process (rm_multi_*): GPU i of n renders every n-th
+    // strip of 8 rows and copies it into the caller's frame; the lightmap patches are split likewise.
+    Engine(const std::vector<EngineObject> &objects, Vec3 camera_position, PointLight light, int width, int height,
+           int map_size, const std::vector<int> &devices)
+        : width_(width), height_(height) {
+        rm_scene *scene = build_scene(objects, camera_position, light);
+        multi_ = rm_multi_create(scene, width, height, map_size, devices.data(), (int)devices.size());
+        rm_scene_destroy(scene);
+        if (!multi_) throw std::runtime_error(std::string("rm_multi_create: ") + rm_last_error());
+        for (int i = 0; i < rm_multi_device_count(multi_); i++) engines_.push_back(rm_multi_engine(multi_, i));
+        handle_ = engines_[0];
+    }
+    ~Engine() {
+        if (multi_)
+            rm_multi_destroy(multi_);
+        else
+            rm_engine_destroy(handle_);
+    }
+    Engine(const Engine &) = delete;
+    Engine &operator=(const Engine &) = delete;
+
+    // engine.rs:246
+    void compute_lightmaps(int bounces = 4) {
+        if (multi_)
+            check(rm_multi_compute_lightmaps(multi_, bounces), "compute_lightmaps");
+        else
+            check(rm_engine_compute_lightmaps(handle_, bounces), "compute_lightmaps");
+    }
+    // the same without any device allocation (work buffers in the library's static array; at most RM_STATIC_MAX_PATCHES patches)
+    void compute_lightmaps_static(int bounces = 4) { check(rm_engine_compute_lightmaps_static(handle_, bounces), "compute_lightmaps_static"); }
+
+    // engine.rs:38-41 (the `directions` scratch argument of the reference is gone)
+    void render(uint8_t *buffer, size_t pitch, int32_t mouse_x, int32_t mouse_y, Vec3 rel_move, int32_t scroll) {
+        if (multi_)
+            check(rm_multi_render(multi_, buffer, pitch, mouse_x, mouse_y, &rel_move.x, scroll), "render");
+        else
+            check(rm_engine_render(handle_, buffer, pitch, mouse_x, mouse_y, &rel_move.x, scroll), "render");
+    }
+
+    // engine.rs:95-108 (commented out there): four rays per pixel
+    void set_ssaa(bool on) { for (rm_engine *e : engines_) check(rm_engine_set_ssaa(e, on ? 4 : 1), "set_ssaa"); }
+
+    // objects.rs:142-149 (commented out there): four-point normals
+    void set_tetrahedral_normals(bool on) { for (rm_engine *e : engines_) check(rm_engine_set_tetrahedral_normals(e, on ? 1 : 0), "set_tetrahedral_normals"); }
+
+    // engine.rs:196-228 (commented out there): reflective objects also refract
+    void set_refraction(bool on) { for (rm_engine *e : engines_) check(rm_engine_set_refraction(e, on ? 1 : 0), "set_refraction"); }
+
+    Vec3 camera_position() const {
+        Vec3 p;
+        check(rm_engine_get_camera(handle_, &p.x), "get_camera");
+        return p;
+    }
+    int width() const { return width_; }
+    int height() const { return height_; }
+    rm_engine *handle() { return handle_; }
+
+   private:
+    // construct_objects() + the Engine literal (main.rs:64-71,154-193) as an rm_scene
+    static rm_scene *build_scene(const std::vector<EngineObject> &objects, Vec3 camera_position, PointLight light) {
         rm_scene *scene = rm_scene_create();
         std::vector<std::pair<const Texture *, int>> textures;
         auto mat = [](const Material &m) { return rm_material{m.ambient, m.diffuse, m.specular, m.shininess, m.reflectivity, m.emissive}; };
@@ -176,44 +242,12 @@ class Engine {
         }
         rm_scene_set_light(scene, &light.position.x, light.intensity);
         rm_scene_set_camera(scene, &camera_position.x);
-        handle_ = rm_engine_create(scene, width, height, map_size, device);
-        rm_scene_destroy(scene);
-        if (!handle_) throw std::runtime_error(std::string("rm_engine_create: ") + rm_last_error());
-    }
-    ~Engine() { rm_engine_destroy(handle_); }
-    Engine(const Engine &) = delete;
-    Engine &operator=(const Engine &) = delete;
-
-    // engine.rs:246
-    void compute_lightmaps(int bounces = 4) { check(rm_engine_compute_lightmaps(handle_, bounces), "compute_lightmaps"); }
-    // the same without any device allocation (work buffers in the library's static array; at most RM_STATIC_MAX_PATCHES patches)
-    void compute_lightmaps_static(int bounces = 4) { check(rm_engine_compute_lightmaps_static(handle_, bounces), "compute_lightmaps_static"); }
-
-    // engine.rs:38-41 (the `directions` scratch argument of the reference is gone)
-    void render(uint8_t *buffer, size_t pitch, int32_t mouse_x, int32_t mouse_y, Vec3 rel_move, int32_t scroll) {
-        check(rm_engine_render(handle_, buffer, pitch, mouse_x, mouse_y, &rel_move.x, scroll), "render");
+        return scene;
     }
 
-    // engine.rs:95-108 (commented out there): four rays per pixel
-    void set_ssaa(bool on) { check(rm_engine_set_ssaa(handle_, on ? 4 : 1), "set_ssaa"); }
-
-    // objects.rs:142-149 (commented out there): four-point normals
-    void set_tetrahedral_normals(bool on) { check(rm_engine_set_tetrahedral_normals(handle_, on ? 1 : 0), "set_tetrahedral_normals"); }
-
-    // engine.rs:196-228 (commented out there): reflective objects also refract
-    void set_refraction(bool on) { check(rm_engine_set_refraction(handle_, on ? 1 : 0), "set_refraction"); }
-
-    Vec3 camera_position() const {
-        Vec3 p;
-        check(rm_engine_get_camera(handle_, &p.x), "get_camera");
-        return p;
-    }
-    int width() const { return width_; }
-    int height() const { return height_; }
-    rm_engine *handle() { return handle_; }
-
-   private:
-    rm_engine *handle_ = nullptr;
+    rm_engine *handle_ = nullptr;       // the engine, or the first of several
+    rm_multi *multi_ = nullptr;         // several GPUs
+    std::vector<rm_engine *> engines_;  // all of them, for the switches
     int width_, height_;
 };
 

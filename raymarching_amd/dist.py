@@ -144,3 +144,12 @@ def _alias_f32(ptr: int, count: int, device: int) -> torch.Tensor:
         __cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
     return torch.as_tensor(_Mem(), device=torch.device("cuda", device))
+
+
+def _alias_u8(ptr: int, count: int, device: int) -> torch.Tensor:
+    """A uint8 CUDA tensor over `count` bytes of existing device memory at `ptr`."""
+
+    class _Mem:
+        __cuda_array_interface__ = {"shape": (count,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    return torch.as_tensor(_Mem(), device=torch.device("cuda", device))

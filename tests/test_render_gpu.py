@@ -206,6 +206,14 @@ def test_headless_host_harness(tmp_path, scene, oracle_lightmaps):
     lm, _ = oracle_lightmaps
     ref = make_oracle(scene, lm[-1]).render(W, H)
     assert_frames_match(got, ref, "headless harness")
+    # the same host with the frame and the lightmap patches spread over "three GPUs" (this one, three
+    # times): the image file is the same byte for byte
+    out3 = tmp_path / "frame3.bmp"
+    res = subprocess.run([exe, "--frames", "2", "--out", str(out3), "--devices", "0,0,0", "--texture",
+                          os.path.join(root, "assets", "textures", "Floor128.bmp")], capture_output=True, text=True, timeout=100)
+    assert res.returncode == 0, res.stderr
+    assert '"gpus": 3' in res.stdout
+    assert out3.read_bytes() == data
 
 
 def test_supersampled_frame(scene, oracle_lightmaps):

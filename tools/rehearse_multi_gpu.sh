@@ -1,13 +1,13 @@
 #!/bin/bash
 # Rehearsal of the several-GPU bench path on a box with one GPU (run there, from the repo root):
-# the packed-strip parity test, the RCCL path with a one-rank group, and 2, 4 and 3 ranks sharing
-# GPU 0 with a gloo exchange (with and without FXAA).  Each run's JSON line lands in gpurun_out/reh/;
+# the packed-strip parity test, the RCCL path (rm_group_frame) with a one-rank group, and 2, 4 and 3
+# ranks sharing GPU 0 with the library's all-gather replaced by gloo through host memory (with and
+# without FXAA).  Each run's JSON line lands in gpurun_out/reh/;
 # "gathered_frame_equals_single_gpu_render" must be true in every one.
 set -o pipefail
 mkdir -p gpurun_out/reh
 timeout -k 10 300 python -u -m pytest tests/test_render_gpu.py -x -q --timeout 120 --timeout-method thread -k "strips" 2>&1 | tail -3 || exit 1
 RM_BENCH_GATHER_ALONE=1 timeout -k 10 200 python bench.py --steps 40 --warmup 5 > gpurun_out/reh/alone.json 2> gpurun_out/reh/alone.err || exit 1
-RM_BENCH_GATHER_ALONE=1 timeout -k 10 200 python bench.py --steps 40 --warmup 5 --no-pack --no-cpu-baseline > gpurun_out/reh/alone_nopack.json 2> gpurun_out/reh/alone.err || exit 1
 RM_BENCH_GATHER_ALONE=1 timeout -k 10 200 python bench.py --steps 20 --warmup 5 --fxaa --width 1920 --height 1080 > gpurun_out/reh/alone_fx.json 2> gpurun_out/reh/alone_fx.err || exit 1
 export RM_BENCH_BACKEND=gloo RM_BENCH_SAME_DEVICE=1
 timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 4 > gpurun_out/reh/g2.json 2> gpurun_out/reh/g2.err || exit 1

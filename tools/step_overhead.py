@@ -1,73 +1,41 @@
-"""Host-side cost of one multi-GPU bench step (launch of a rank's strips, asynchronous all-gather,
-wait, re-ordering copy), measured with a one-rank RCCL group on one GPU: the GPU work is an eighth
-of a frame, so the loop shows how many steps per second the host can issue.
+"""Host-side cost of one frame of a several-GPU run: rm_group_frame (a rank's strips, pack, RCCL
+all-gather on the frame's stream, unpack) issued through ctypes, measured with a one-rank RCCL group
+on one GPU.  The GPU work per call is about an eighth of a 3840x2160 frame, so the issue rate shows
+what the host can sustain.
 Run on the GPU box: python tools/step_overhead.py"""
+import ctypes
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29533")
 import torch
-import torch.distributed as dist
 
-from raymarching_amd import Engine, default_scene
-from raymarching_amd.dist import deinterleave_strips, strip_plan
+from raymarching_amd import Engine, _lib, default_scene
+from raymarching_amd.group import Group, unique_id
 
-W, H, SHARE = 3840, 2160, 8
-dist.init_process_group("nccl", rank=0, world_size=1)
-eng = Engine(default_scene(), W, H)
-main = torch.cuda.current_stream()
-eng.set_stream(main.cuda_stream)
+W, H = 3840, 2160
+# an eighth of the frame's strips: an engine of one eighth of the height renders as many tiles as one
+# of eight ranks would (the per-call host work does not depend on which strips they are)
+eng = Engine(default_scene(), W, H // 8)
 eng.compute_lightmaps(4)
-eng.input(0, 0, (0.0, 0.0, 0.0), 0)
-first, stride, per = strip_plan(H, 0, SHARE)
-K = 3
-streams = [torch.cuda.Stream() for _ in range(K)]
-bands = [torch.zeros((per * 8, W, 4), dtype=torch.uint8, device="cuda") for _ in range(K)]
-gathered = [torch.zeros((per * 8, W, 4), dtype=torch.uint8, device="cuda") for _ in range(K)]
-# the re-ordering copy of a whole frame (what an 8-rank run does per frame)
-frames = [torch.zeros((SHARE * per * 8, W, 4), dtype=torch.uint8, device="cuda") for _ in range(K)]
-final = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(K)]
-
-
-def run(n, parts):
-    t = dict.fromkeys(("render", "gather", "wait", "reorder"), 0.0)
-    pending = [None] * K
-    for s in range(n):
-        b = s % K
-        with torch.cuda.stream(streams[b]):
-            t0 = time.perf_counter()
-            if pending[b] is not None:
-                pending[b].wait()
-            t1 = time.perf_counter()
-            if pending[b] is not None and "reorder" in parts:
-                final[b].copy_(deinterleave_strips(frames[b], SHARE, per, W, H))
-            t2 = time.perf_counter()
-            eng.set_stream(streams[b].cuda_stream)
-            eng.render_strips_device(bands[b].data_ptr(), first, stride, per)
-            t3 = time.perf_counter()
-            if "gather" in parts:
-                pending[b] = dist.all_gather_into_tensor(gathered[b].view(-1), bands[b].view(-1), async_op=True)
-            t4 = time.perf_counter()
-        t["wait"] += t1 - t0
-        t["reorder"] += t2 - t1
-        t["render"] += t3 - t2
-        t["gather"] += t4 - t3
-    return t
-
-
-for parts in (("render",), ("render", "gather"), ("render", "gather", "reorder")):
-    run(30, parts)
-    torch.cuda.synchronize()
-    n = 300
-    t0 = time.perf_counter()
-    t = run(n, parts)
-    issue = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    total = time.perf_counter() - t0
-    print(f"{'+'.join(parts):24s} issue {issue / n * 1e6:6.1f} us/step, with GPU drain {total / n * 1e6:6.1f} us/step;  "
-          + "  ".join(f"{k} {v / n * 1e6:.1f}" for k, v in t.items()), flush=True)
+out = [torch.zeros((H // 8, W, 4), dtype=torch.uint8, device="cuda") for _ in range(4)]
+lib = _lib.load()
+zero = _lib.f3((0.0, 0.0, 0.0))
+for in_flight in (1, 3):
+    grp = Group(eng, 0, 1, unique_id(), frames_in_flight=in_flight)
+    for fxaa in (0, 1):
+        for _ in range(30):
+            grp.frame(out[0].data_ptr(), bool(fxaa))
+        grp.wait()
+        n = 400
+        ptrs = [ctypes.c_void_p(o.data_ptr()) for o in out]
+        t0 = time.perf_counter()
+        for s in range(n):
+            lib.rm_group_frame(grp.handle, ptrs[s & 3], fxaa, 0, 0, zero, 0)
+        issue = time.perf_counter() - t0
+        grp.wait()
+        total = time.perf_counter() - t0
+        print(f"frames in flight {in_flight}, fxaa {fxaa}: issue {issue / n * 1e6:6.1f} us/frame, with GPU drain {total / n * 1e6:6.1f} us/frame", flush=True)
+    grp.close()
 eng.close()
-dist.destroy_process_group()
