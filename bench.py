@@ -322,9 +322,9 @@ def main():
     eng.set_stream(stream.cuda_stream)
     if args.workload == "stress":
         # boxes have no lightmap parameterisation: a fixed smooth pattern stands in for the precompute
-        u, v = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
-        lm = np.stack([0.10 + 0.02 * u, 0.12 + 0.01 * v, 0.08 + 0.01 * (u + v)], axis=-1).astype(np.float32)
-        from raymarching_amd.scene import Box
+        from raymarching_amd.scene import Box, stress_lightmap_pattern
+
+        lm = stress_lightmap_pattern()
 
         for i, obj in enumerate(scene.objects):
             if not isinstance(obj, Box):

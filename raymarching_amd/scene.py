@@ -275,3 +275,10 @@ def stress_scene(n_spheres: int = 250, seed: int = 0xC0FFEE, texture_path: Optio
     ]
     return Scene(objects=objects, camera_position=(0.0, 0.5, -3.5), light=PointLight((2.0, -1.0, 1.5), 3.5),
                  smooth_union=smooth_union)
+
+
+def stress_lightmap_pattern(map_size: int = 8) -> np.ndarray:
+    """A fixed smooth [M][M][3] pattern that stands in for the lightmap precompute in scenes whose
+    boxes have no lightmap parameterisation (bench.py --workload stress and its parity test)."""
+    u, v = np.meshgrid(np.arange(map_size), np.arange(map_size), indexing="ij")
+    return np.stack([0.10 + 0.02 * u, 0.12 + 0.01 * v, 0.08 + 0.01 * (u + v)], axis=-1).astype(np.float32)

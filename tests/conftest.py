@@ -65,8 +65,23 @@ def frame_stats(a, b):
     return int(d.max()), float(exact)
 
 
-def assert_frames_match(gpu, ref, what=""):
+# What the kernels actually deliver, asserted next to the contract above so that a regression inside
+# the contract still fails: no channel off by more than 1, and no more than one pixel in 100 000 (or
+# four pixels of a small frame) off at all.  Only powf and atan2f - the two calls whose last bit is the
+# platform's - can move a pixel.
+STRICT_MAX_ABS_DIFF = 1
+STRICT_MAX_INEXACT_FRACTION = 1e-5
+STRICT_MAX_INEXACT_PIXELS = 4
+
+
+def assert_frames_match(gpu, ref, what="", strict=True):
     mx, exact = frame_stats(gpu, ref)
     assert mx <= MAX_ABS_DIFF, f"{what}: max |delta| {mx} > {MAX_ABS_DIFF}"
     assert exact >= MIN_EXACT_FRACTION, f"{what}: only {exact:.5%} of pixels exact"
+    if strict:
+        pixels = gpu.shape[0] * gpu.shape[1]
+        inexact = round((1.0 - exact) * pixels)
+        assert mx <= STRICT_MAX_ABS_DIFF, f"{what}: max |delta| {mx} > {STRICT_MAX_ABS_DIFF} (inside the contract, beyond what the kernels deliver)"
+        assert inexact <= max(STRICT_MAX_INEXACT_PIXELS, STRICT_MAX_INEXACT_FRACTION * pixels), (
+            f"{what}: {inexact} of {pixels} pixels differ (inside the contract, beyond what the kernels deliver)")
     return mx, exact

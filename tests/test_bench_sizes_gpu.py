@@ -1,0 +1,134 @@
+"""Parity at the sizes bench.py measures: the 3840x2160 default frame, the 1920x1080 frame with FXAA,
+rows of the 7680x4320 stress frame, and the lightmaps at a MAP_SIZE whose bounce runs over several
+slabs of form factors.  The oracle renders these in seconds (whole 4K frame: a few seconds of CPU;
+the stress scene: eight rows)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_frames_match, frame_stats, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+THREADS = min(os.cpu_count() or 1, 16)
+
+
+def test_default_frame_at_3840x2160(scene, oracle_lightmaps):
+    """BASELINE's headline configuration: every pixel of the 4K frame against the oracle."""
+    from raymarching_amd import Engine
+
+    w, h = 3840, 2160
+    lm, _ = oracle_lightmaps
+    eng = Engine(scene, w, h)
+    eng.compute_lightmaps(4)
+    for i in range(eng.n_objects):
+        assert np.array_equal(eng.get_lightmap(i).view(np.uint32), lm[-1][i].view(np.uint32))
+    got = eng.render()
+    st = eng.stats()
+    eng.close()
+    ora = make_oracle(scene, lm[-1])
+    ref = ora.render(w, h, threads=THREADS)
+    ora.close()
+    mx, exact = assert_frames_match(got, ref, "3840x2160")
+    print(f"3840x2160: max|d| = {mx}, {round((1 - exact) * w * h)} of {w * h} pixels differ")
+    assert st["depth_cap_hits"] == 0 and st["lightmap_oob"] == 0
+
+
+def test_1080p_render_then_fxaa_chain(scene, oracle_lightmaps):
+    """Config "1920x1080 with shading + texture + FXAA": GPU render -> GPU FXAA against oracle render ->
+    oracle FXAA.  The filter itself is exact (GPU FXAA of a frame == oracle FXAA of the same frame);
+    end to end the chain inherits the renderer's one-in-a-million powf/atan2f pixels and nothing else."""
+    import torch
+
+    import oracle
+    from raymarching_amd import Engine
+
+    w, h = 1920, 1080
+    lm, _ = oracle_lightmaps
+    eng = Engine(scene, w, h)
+    for i in range(eng.n_objects):
+        eng.set_lightmap(i, lm[-1][i])
+    raw = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    filt = torch.zeros_like(raw)
+    eng.input(0, 0, (0.0, 0.0, 0.0), 0)
+    eng.render_rows_device(raw.data_ptr(), 0, h)
+    eng.fxaa_device(raw.data_ptr(), filt.data_ptr(), 0, h)
+    eng.synchronize()
+    gpu_raw, gpu_filt = raw.cpu().numpy(), filt.cpu().numpy()
+    eng.close()
+    ora = make_oracle(scene, lm[-1])
+    ref_raw = ora.render(w, h, threads=THREADS)
+    ora.close()
+    ref_filt = oracle.fxaa(ref_raw)
+    assert np.array_equal(gpu_filt, oracle.fxaa(gpu_raw)), "the filter alone must be exact"
+    assert not np.array_equal(gpu_filt, gpu_raw), "the filter changes the frame"
+    mx_raw, exact_raw = assert_frames_match(gpu_raw, ref_raw, "1920x1080 render")
+    mx, exact = assert_frames_match(gpu_filt, ref_filt, "1920x1080 render + FXAA")
+    if np.array_equal(gpu_raw, ref_raw):
+        assert np.array_equal(gpu_filt, ref_filt)
+    print(f"1080p chain: render {round((1 - exact_raw) * w * h)} pixels off (max {mx_raw}), after FXAA {round((1 - exact) * w * h)} (max {mx})")
+
+
+def test_stress_frame_rows_at_7680x4320():
+    """Config "256 mixed primitives with smooth unions, 7680x4320, march cap 1024": eight rows spread
+    over the frame against the oracle's full fold over all primitives, no march cut by the cap, and
+    the whole frame bit-stable from run to run."""
+    import torch
+
+    from raymarching_amd import Engine
+    from raymarching_amd.scene import Box, stress_lightmap_pattern, stress_scene
+
+    w, h = 7680, 4320
+    scene = stress_scene(250, boxes=True, smooth_union=0.08)
+    lm = stress_lightmap_pattern()
+    eng = Engine(scene, w, h)
+    ora = make_oracle(scene)
+    for i, obj in enumerate(scene.objects):
+        if not isinstance(obj, Box):
+            eng.set_lightmap(i, lm)
+            ora.set_lightmap(i, lm)
+    eng.set_march_cap(1024)
+    frame = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    eng.input(0, 0, (0.0, 0.0, 0.0), 0)
+    digests = []
+    for _ in range(2):
+        eng.render_rows_device(frame.data_ptr(), 0, h)
+        eng.synchronize()
+        host = frame.cpu().numpy()
+        digests.append(hashlib.sha256(host.tobytes()).hexdigest())
+    assert digests[0] == digests[1], "the frame must be bit-stable from run to run"
+    st = eng.stats()
+    assert st["step_cap_hits"] == 0 and st["depth_cap_hits"] == 0 and st["lightmap_oob"] == 0, st
+    eng.close()
+    rows = [5, 611, 1500, 2160, 2701, 3333, 3900, 4319]
+    worst, off = 0, 0
+    for y in rows:
+        ref = ora.render(w, h, rows=(y, y + 1), threads=THREADS)
+        mx, exact = frame_stats(host[y:y + 1], ref)
+        worst, off = max(worst, mx), off + round((1 - exact) * w)
+    ora.close()
+    print(f"7680x4320 stress rows {rows}: max|d| = {worst}, {off} of {len(rows) * w} pixels differ")
+    assert worst <= 1 and off <= 4
+
+
+def test_lightmaps_at_map_size_16(scene):
+    """MAP_SIZE 16: 2048 patches, so a bounce folds 32 slabs of form factors per receiver and the sources
+    of a form-factor launch span several chunks (RM_RAD_CHUNK) - bit for bit against the oracle."""
+    from raymarching_amd import Engine
+
+    os.environ["RM_RAD_CHUNK"] = "700"
+    try:
+        eng = Engine(scene, 64, 64, map_size=16)
+        eng.compute_lightmaps(4)
+    finally:
+        del os.environ["RM_RAD_CHUNK"]
+    got = np.stack([eng.get_lightmap(i) for i in range(eng.n_objects)])
+    eng.close()
+    ora = make_oracle(scene, map_size=16)
+    ora.compute_lightmaps(4)
+    ref = np.stack([ora.get_lightmap(i) for i in range(ora.n_objects)])
+    ora.close()
+    assert np.abs(ref).max() > 0
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

@@ -19,6 +19,7 @@ def test_random_poses_and_scenes(seed):
 
     frames, worst, inexact = random_parity.run(n_poses=12, n_scenes=5, seed=seed, verbose=False)
     print(f"seed {seed}: {frames} frames, worst max|d| = {worst}, worst inexact fraction = {inexact:.2e}")
-    # the tolerance of tests/conftest.py: 2/255 per channel, 99.9 % of the pixels exact
+    # the contract is 2/255 per channel and 99.9 % of the pixels exact; what the kernels deliver, and
+    # what is asserted, is the strict tier of tests/conftest.py: off by 1 at most, in 4 of the 76800 pixels at most
     assert frames == 12 + 5 * 4
-    assert worst <= 2 and inexact <= 1e-3
+    assert worst <= 1 and inexact <= 4 / (320 * 240)
