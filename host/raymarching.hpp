@@ -176,6 +176,10 @@ class Engine {
     // the same without any device allocation (work buffers in the library's static array; at most RM_STATIC_MAX_PATCHES patches)
     void compute_lightmaps_static(int bounces = 4) { check(rm_engine_compute_lightmaps_static(handle_, bounces), "compute_lightmaps_static"); }
 
+    // all lightmaps to / from one file, to skip the precompute at the next start (the reference recomputes, main.rs:73)
+    void save_lightmaps(const std::string &path) { check(rm_engine_save_lightmaps(handle_, path.c_str()), "save_lightmaps"); }
+    void load_lightmaps(const std::string &path) { for (rm_engine *e : engines_) check(rm_engine_load_lightmaps(e, path.c_str()), "load_lightmaps"); }
+
     // engine.rs:38-41 (the `directions` scratch argument of the reference is gone)
     void render(uint8_t *buffer, size_t pitch, int32_t mouse_x, int32_t mouse_y, Vec3 rel_move, int32_t scroll) {
         if (multi_)

@@ -93,10 +93,16 @@ int rm_scene_add_xplane(rm_scene *scene, float x, float dir, const rm_material *
 int rm_scene_add_yplane(rm_scene *scene, float y, float dir, const rm_material *material, const float colour[3],
                         int texture);
 int rm_scene_add_zplane(rm_scene *scene, float z, float dir, const rm_material *material, const float colour[3]);
-/* The reference cannot light or shade a generic Plane (its get_sample_pos and
- * sample_uv_from_pos are unimplemented!(), objects.rs:39-42).  Here a Plane is
- * rendered with the no-lightmap ambient of engine.rs:158 and takes no part in
- * the radiosity clouds. */
+/* The reference gives a generic Plane a lightmap (plane_funcs!, objects.rs:216) but no way to address
+ * it: get_sample_pos and sample_uv_from_pos are unimplemented!() (objects.rs:39-42), so lighting or
+ * shading one aborts.  Defined here (an extension, the same in the CPU oracle): the lightmap lies over
+ * two tangent directions through the plane's point nearest the origin, origin = normal * distance, with
+ * a = the axis of the largest |normal component|, e1 < e2 the other two axes,
+ * t = normalized(unit(e1) - normal * normal[e1]), b = normal x t (negated if its e2 component is
+ * negative): get_sample_pos(u, v) = origin + t (u - M/2 + 0.5) + b (v - M/2 + 0.5) and
+ * sample_uv_from_pos(p) = ((p - origin).t + M/2 - 0.5, (p - origin).b + M/2 - 0.5).  A Plane with an
+ * axis normal thereby gets exactly the lightmap of the matching XPlane / YPlane / ZPlane.  The normal
+ * is taken as given (unit length expected, as the reference's sdf expects it). */
 int rm_scene_add_plane(rm_scene *scene, const float normal[3], float distance, const rm_material *material,
                        const float colour[3]);
 
@@ -165,6 +171,14 @@ int rm_engine_compute_lightmaps_static(rm_engine *engine, int bounces);
  * `values` is [map_size][map_size][3] float, first index u (as sample_map[u][v]). */
 int rm_engine_get_lightmap(rm_engine *engine, int object, float *values);
 int rm_engine_set_lightmap(rm_engine *engine, int object, const float *values);
+
+/* The reference recomputes its lightmaps at every start (main.rs:73) and keeps them nowhere.  These
+ * two write and read all lightmaps of an engine as one small file (6 KiB for the default scene:
+ * magic, version, map_size, count, then object index and [map_size][map_size][3] floats per
+ * lightmap), so that a host can skip the precompute.  Loading checks map_size, the lightmap count and
+ * the object each lightmap belongs to, and changes nothing when the file does not fit. */
+int rm_engine_save_lightmaps(rm_engine *engine, const char *path);
+int rm_engine_load_lightmaps(rm_engine *engine, const char *path);
 
 /* The camera block of Engine::render (engine.rs:63-75): accumulated mouse
  * position and scroll, and this frame's movement.  Stateful exactly as the

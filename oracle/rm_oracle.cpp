@@ -479,26 +479,59 @@ struct Sphere : EngineObject {
     }
 };
 
-// objects.rs:167-175, 259-264.  get_sample_pos / sample_uv_from_pos are NOT
-// implemented for Plane in the reference: lighting or shading one aborts.
+// objects.rs:167-175, 259-264.  plane_funcs!() gives Plane a lightmap (objects.rs:216), but
+// get_sample_pos / sample_uv_from_pos are NOT implemented for it in the reference: lighting or
+// shading one aborts (unimplemented!(), objects.rs:39,42).
+//
+// EXTENSION, defined here and in the HIP library alike: the lightmap of a Plane is laid out over two
+// tangent directions through the plane's point nearest the origin, chosen so that a Plane with an
+// axis normal gets the parameterisation of the matching XPlane / YPlane / ZPlane:
+//   a  = the axis of the largest |normal component| (lowest on ties); e1 < e2 the other two axes
+//   t  = normalized(unit(e1) - normal * normal[e1])
+//   b  = (normal x t), negated if its e2 component is negative
+//   origin = normal * distance
+//   get_sample_pos(u, v)   = (origin + t * ((u - M/2) + 0.5)) + b * ((v - M/2) + 0.5)
+//   sample_uv_from_pos(p)  = ((p - origin).t + M/2 - 0.5, (p - origin).b + M/2 - 0.5)
+// all in f32, in the order written.
 struct Plane : EngineObject {
     Vec3 normal;
     float distance = 0.0f;
-    // plane_funcs!() gives Plane a lightmap (objects.rs:216), so shading one calls the
-    // unimplemented sample_uv_from_pos and aborts.  Stand-in used here and by the HIP
-    // library alike: treat it as an object without a lightmap (engine.rs:158).
-    explicit Plane(int m) : EngineObject(m) {
-        type = T_PLANE;
-        has_lightmap = false;
-    }
+    Vec3 tangent, bitangent, origin;
+    explicit Plane(int m) : EngineObject(m) { type = T_PLANE; }
     float sdf(const Vec3 &p) const override { return p.dot(normal) - distance; }  // :261
     bool radiosity_collide() const override { return true; }
+    void set_up_lightmap_axes() {
+        const float n[3] = {normal.x(), normal.y(), normal.z()};
+        int a = 0;
+        if (std::fabs(n[1]) > std::fabs(n[a])) a = 1;
+        if (std::fabs(n[2]) > std::fabs(n[a])) a = 2;
+        const int e1 = a == 0 ? 1 : 0, e2 = a == 2 ? 1 : 2;
+        const float d1 = n[e1];
+        Vec3 raw((e1 == 0 ? 1.0f : 0.0f) - n[0] * d1, (e1 == 1 ? 1.0f : 0.0f) - n[1] * d1, (e1 == 2 ? 1.0f : 0.0f) - n[2] * d1);
+        tangent = raw.normalized();
+        const float t[3] = {tangent.x(), tangent.y(), tangent.z()};
+        float c[3] = {n[1] * t[2] - n[2] * t[1], n[2] * t[0] - n[0] * t[2], n[0] * t[1] - n[1] * t[0]};
+        const float sgn = c[e2] < 0.0f ? -1.0f : 1.0f;
+        bitangent = Vec3(c[0] * sgn, c[1] * sgn, c[2] * sgn);
+        origin = normal * distance;
+    }
+    Vec3 get_sample_pos(uint64_t u, uint64_t v, bool &) const override {
+        const float MS = (float)lightmap.m;
+        const float a = ((float)u) - (MS / 2.0f) + 0.5f, b = ((float)v) - (MS / 2.0f) + 0.5f;
+        return (origin + tangent * a) + bitangent * b;
+    }
+    void sample_uv_from_pos(const Vec3 &pos, float &u, float &v, bool &) const override {
+        const float MS = (float)lightmap.m;
+        const Vec3 rel = pos - origin;
+        u = rel.dot(tangent) + (MS / 2.0f) - 0.5f;
+        v = rel.dot(bitangent) + (MS / 2.0f) - 0.5f;
+    }
 };
 
 // EXTENSION (not live code in the reference): the box distance of the commented-out block
 // objects.rs:370-380, with the centre and the half extents as parameters (the text has the
-// half extents fixed at 0.7).  Evaluation order as written there.  Like Plane it has no
-// lightmap parameterisation, so it is shaded with the no-lightmap ambient of engine.rs:158.
+// half extents fixed at 0.7).  Evaluation order as written there.  It has no lightmap
+// parameterisation, so it is shaded with the no-lightmap ambient of engine.rs:158.
 struct Box : EngineObject {
     Vec3 position, half;
     explicit Box(int m) : EngineObject(m) {
@@ -1229,6 +1262,7 @@ int orc_add_plane(void *h, const float *normal, float distance, const float *mat
     auto s = std::make_unique<Plane>(e->map_size);
     s->normal = Vec3(normal[0], normal[1], normal[2]);
     s->distance = distance;
+    s->set_up_lightmap_axes();
     set_common(*s, mat, colour);
     e->objects.push_back(std::move(s));
     return (int)e->objects.size() - 1;

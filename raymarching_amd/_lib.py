@@ -54,6 +54,8 @@ SIGNATURES = {
     "rm_engine_radiosity_buffers": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int)]),
     "rm_engine_get_lightmap": (c_int, [c_void_p, c_int, POINTER(c_float)]),
     "rm_engine_set_lightmap": (c_int, [c_void_p, c_int, POINTER(c_float)]),
+    "rm_engine_save_lightmaps": (c_int, [c_void_p, c_char_p]),
+    "rm_engine_load_lightmaps": (c_int, [c_void_p, c_char_p]),
     "rm_engine_input": (c_int, [c_void_p, c_int32, c_int32, _F3, c_int32]),
     "rm_engine_get_camera": (c_int, [c_void_p, _F3]),
     "rm_engine_set_camera": (c_int, [c_void_p, _F3]),

@@ -833,10 +833,18 @@ RM_DEV void sample_uv_from_pos(int type, const Geom &g, V3 pos, float ms, float 
             u = pos.x + half - 0.5f;
             v = pos.z + half - 0.5f;
             return;
-        default:  // T_ZPLANE
+        case T_ZPLANE:
             u = pos.x + half - 0.5f;
             v = pos.y + half - 0.5f;
             return;
+        default: {  // T_PLANE (no counterpart in the reference, objects.rs:42): p = normal, distance, tangent, sign of the bitangent
+            const V3 n = v3(g.p[0], g.p[1], g.p[2]), t = v3(g.p[4], g.p[5], g.p[6]);
+            const V3 b = v3(n.y * t.z - n.z * t.y, n.z * t.x - n.x * t.z, n.x * t.y - n.y * t.x) * g.p[7];
+            const V3 rel = pos - n * g.p[3];
+            u = dot(rel, t) + half - 0.5f;
+            v = dot(rel, b) + half - 0.5f;
+            return;
+        }
     }
 }
 

@@ -804,6 +804,13 @@ static bool host_sample_pos(const HostObject &o, int M, int u, int v, float out[
         case T_XPLANE: out[0] = o.p[0]; out[1] = a; out[2] = b; return true;
         case T_YPLANE: out[0] = a; out[1] = o.p[0]; out[2] = b; return true;
         case T_ZPLANE: out[0] = a; out[1] = b; out[2] = o.p[0]; return true;
+        case T_PLANE: {
+            // (origin + t * a) + bitangent * b, origin = normal * distance (see rm_scene_add_plane)
+            const float *n = o.p, *t = o.p + 4, sgn = o.p[7];
+            const float c[3] = {(n[1] * t[2] - n[2] * t[1]) * sgn, (n[2] * t[0] - n[0] * t[2]) * sgn, (n[0] * t[1] - n[1] * t[0]) * sgn};
+            for (int k = 0; k < 3; k++) out[k] = (n[k] * o.p[3] + t[k] * a) + c[k] * b;
+            return true;
+        }
         default: return false;
     }
 }
@@ -842,7 +849,7 @@ static int engine_upload(rm_engine *e) {
         r.type = o.type;
         r.texture = o.texture;
         r.textured = (o.type == T_YPLANE && !(o.p[0] > 0.0f)) ? 1 : 0;  // objects.rs:268
-        if (o.type != T_PLANE && o.type != T_BOX) {
+        if (o.type != T_BOX) {
             r.lm_slot = (int)e->patch_obj.size();
             e->lm_slot[i] = r.lm_slot;
             e->patch_obj.push_back(i);
@@ -1425,6 +1432,25 @@ int rm_scene_add_plane(rm_scene *scene, const float normal[3], float distance, c
                        const float colour[3]) {
     if (!normal) return -fail(RM_ERR_INVALID, "NULL normal");
     float p[8] = {normal[0], normal[1], normal[2], distance};
+    // The lightmap of a Plane (the reference gives it one, objects.rs:216, and no way to address it,
+    // objects.rs:39,42) lies over two tangent directions, chosen so that an axis normal reproduces the
+    // layout of the matching XPlane / YPlane / ZPlane: a = axis of the largest |normal component|,
+    // e1 < e2 the other two; t = normalized(unit(e1) - normal * normal[e1]); b = normal x t, negated if
+    // its e2 component is negative.  t and that sign travel with the geometry (p[4..7]).
+    const float *n = normal;
+    int a = 0;
+    if (fabsf(n[1]) > fabsf(n[a])) a = 1;
+    if (fabsf(n[2]) > fabsf(n[a])) a = 2;
+    const int e1 = a == 0 ? 1 : 0, e2 = a == 2 ? 1 : 2;
+    const float d1 = n[e1];
+    const float raw[3] = {(e1 == 0 ? 1.0f : 0.0f) - n[0] * d1, (e1 == 1 ? 1.0f : 0.0f) - n[1] * d1, (e1 == 2 ? 1.0f : 0.0f) - n[2] * d1};
+    const float inv = 1.0f / sqrtf((raw[0] * raw[0] + raw[1] * raw[1]) + raw[2] * raw[2]);  // vector.rs:27-30
+    const float t[3] = {raw[0] * inv, raw[1] * inv, raw[2] * inv};
+    const float c[3] = {n[1] * t[2] - n[2] * t[1], n[2] * t[0] - n[0] * t[2], n[0] * t[1] - n[1] * t[0]};
+    p[4] = t[0];
+    p[5] = t[1];
+    p[6] = t[2];
+    p[7] = c[e2] < 0.0f ? -1.0f : 1.0f;
     return add_object(scene, T_PLANE, p, material, colour, -1);
 }
 int rm_scene_add_box(rm_scene *scene, const float position[3], const float half_extent[3], const rm_material *material,
@@ -2013,6 +2039,58 @@ int rm_engine_set_lightmap(rm_engine *e, int object, const float *values) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (int rc_ = quiesce_frames_in_flight(e)) return rc_;  // frames in flight still sample the old values
     HIP_TRY(hipMemcpy(e->d_lightmaps + slot * count, values, count * sizeof(float), hipMemcpyHostToDevice));
+    return RM_OK;
+}
+
+// Lightmap file: "RMLM", u32 version (1), u32 map_size, u32 lightmap count, then per lightmap the u32
+// object index and map_size * map_size * 3 f32 values, first index u (sample_map[u][v]); little endian.
+int rm_engine_save_lightmaps(rm_engine *e, const char *path) {
+    if (!e || !path) return fail(RM_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<float> all((size_t)e->n_patches * 3);
+    if (!all.empty()) HIP_TRY(hipMemcpy(all.data(), e->d_lightmaps, all.size() * sizeof(float), hipMemcpyDeviceToHost));
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(RM_ERR_INVALID, std::string("cannot write ") + path);
+    const uint32_t head[4] = {0x4D4C4D52u /* "RMLM" */, 1u, (uint32_t)e->M, (uint32_t)e->n_lm};
+    bool ok = fwrite(head, sizeof(head), 1, f) == 1;
+    const size_t per = (size_t)e->M * e->M * 3;
+    for (int slot = 0; slot < e->n_lm && ok; slot++) {
+        const uint32_t obj = (uint32_t)e->patch_obj[slot];
+        ok = fwrite(&obj, sizeof(obj), 1, f) == 1 && fwrite(all.data() + slot * per, sizeof(float), per, f) == per;
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? RM_OK : fail(RM_ERR_INVALID, std::string("short write to ") + path);
+}
+
+int rm_engine_load_lightmaps(rm_engine *e, const char *path) {
+    if (!e || !path) return fail(RM_ERR_INVALID, "NULL argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(RM_ERR_INVALID, std::string("cannot read ") + path);
+    uint32_t head[4] = {0, 0, 0, 0};
+    const size_t per = (size_t)e->M * e->M * 3;
+    std::vector<float> all((size_t)e->n_patches * 3);
+    std::string why;
+    if (fread(head, sizeof(head), 1, f) != 1 || head[0] != 0x4D4C4D52u || head[1] != 1u)
+        why = "not a lightmap file (version 1)";
+    else if (head[2] != (uint32_t)e->M || head[3] != (uint32_t)e->n_lm)
+        why = "the file holds " + std::to_string(head[3]) + " lightmaps of size " + std::to_string(head[2]) + ", the engine " +
+              std::to_string(e->n_lm) + " of size " + std::to_string(e->M);
+    for (int slot = 0; slot < e->n_lm && why.empty(); slot++) {
+        uint32_t obj = 0;
+        if (fread(&obj, sizeof(obj), 1, f) != 1 || fread(all.data() + slot * per, sizeof(float), per, f) != per)
+            why = "the file ends early";
+        else if (obj != (uint32_t)e->patch_obj[slot])
+            why = "lightmap " + std::to_string(slot) + " belongs to object " + std::to_string(obj) + ", the engine expects object " +
+                  std::to_string(e->patch_obj[slot]);
+    }
+    if (why.empty() && fgetc(f) != EOF) why = "trailing bytes";
+    fclose(f);
+    if (!why.empty()) return fail(RM_ERR_INVALID, std::string(path) + ": " + why);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (int rc_ = quiesce_frames_in_flight(e)) return rc_;  // frames in flight still sample the old values
+    if (!all.empty()) HIP_TRY(hipMemcpy(e->d_lightmaps, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
     return RM_OK;
 }
 

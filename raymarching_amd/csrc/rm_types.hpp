@@ -20,7 +20,7 @@ constexpr int MAX_DEPTH = 16;  // explicit reflection stack (the reference recur
 // Geometry of one object, 32 bytes.
 //   sphere      : cx, cy, cz, radius
 //   axis plane  : offset, dir
-//   plane       : nx, ny, nz, distance
+//   plane       : nx, ny, nz, distance, tx, ty, tz (lightmap tangent), sign of the bitangent normal x tangent
 //   box         : cx, cy, cz, hx, hy, hz   (centre, half extents)
 struct Geom {
     float p[8];
@@ -33,7 +33,7 @@ struct ShadeRec {
     int type;
     int texture;   // texture id or -1
     int textured;  // YPlane with !(y > 0): colour comes from the texture (objects.rs:267-274)
-    int lm_slot;   // index of this object's lightmap, -1 = none (generic Plane)
+    int lm_slot;   // index of this object's lightmap, -1 = none (box)
     int pad[3];
 };
 static_assert(sizeof(ShadeRec) == 64, "ShadeRec layout");

@@ -141,6 +141,13 @@ class Engine:
         v = np.ascontiguousarray(values, dtype=np.float32).reshape(self.map_size, self.map_size, 3)
         _lib.check(self.lib.rm_engine_set_lightmap(self.handle, obj, v.ctypes.data_as(POINTER(c_float))), "rm_engine_set_lightmap")
 
+    def save_lightmaps(self, path):
+        """All lightmaps into one file (the reference keeps none: main.rs:73 recomputes them at every start)."""
+        _lib.check(self.lib.rm_engine_save_lightmaps(self.handle, str(path).encode()), "rm_engine_save_lightmaps")
+
+    def load_lightmaps(self, path):
+        _lib.check(self.lib.rm_engine_load_lightmaps(self.handle, str(path).encode()), "rm_engine_load_lightmaps")
+
     # -- camera (engine.rs:63-75) ------------------------------------------
     def input(self, mouse_x=0, mouse_y=0, rel_move=(0.0, 0.0, 0.0), scroll=0):
         _lib.check(self.lib.rm_engine_input(self.handle, mouse_x, mouse_y, _lib.f3(rel_move), scroll), "rm_engine_input")

@@ -144,3 +144,41 @@ def test_patch_sharded_precompute_two_processes(tmp_path, oracle_lightmaps):
     for r in range(2):
         got = np.load(str(tmp_path / f"lm_{r}.npy"))
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_lightmaps_saved_and_loaded(tmp_path, scene):
+    """rm_engine_save_lightmaps / _load_lightmaps: a second engine that loads the file renders the same
+    frame without running the precompute; files that do not fit are refused and change nothing."""
+    from raymarching_amd import Engine, _lib
+
+    eng = Engine(scene, 160, 120)
+    eng.compute_lightmaps(4)
+    want = np.stack([eng.get_lightmap(i) for i in range(eng.n_objects)])
+    frame = eng.render()
+    path = tmp_path / "lightmaps.rmlm"
+    eng.save_lightmaps(path)
+    assert path.stat().st_size == 16 + 8 * (4 + 8 * 8 * 3 * 4)
+    eng.close()
+    other = Engine(scene, 160, 120)
+    other.load_lightmaps(path)
+    got = np.stack([other.get_lightmap(i) for i in range(other.n_objects)])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(other.render(), frame)
+    # refused: another map size, a truncated file, something that is no lightmap file
+    big = Engine(scene, 64, 64, map_size=16)
+    with pytest.raises(_lib.RMError, match="of size 8, the engine 8 of size 16"):
+        big.load_lightmaps(path)
+    big.close()
+    cut = tmp_path / "cut.rmlm"
+    cut.write_bytes(path.read_bytes()[:-100])
+    with pytest.raises(_lib.RMError, match="ends early"):
+        other.load_lightmaps(cut)
+    junk = tmp_path / "junk.rmlm"
+    junk.write_bytes(b"BM" + bytes(64))
+    with pytest.raises(_lib.RMError, match="not a lightmap file"):
+        other.load_lightmaps(junk)
+    with pytest.raises(_lib.RMError, match="cannot read"):
+        other.load_lightmaps(tmp_path / "missing.rmlm")
+    got = np.stack([other.get_lightmap(i) for i in range(other.n_objects)])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    other.close()

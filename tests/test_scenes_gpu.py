@@ -92,16 +92,14 @@ def _compare(scene, w=W, h=H, pose=(0, 0, (0.0, 0.0, 0.0), 0), lightmaps=True, r
         u, v = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
         lm = np.stack([0.10 + 0.02 * u, 0.12 + 0.01 * v, 0.08 + 0.01 * (u + v)], axis=-1).astype(np.float32)
         for i in range(eng.n_objects):
-            if not isinstance(scene.objects[i], (Plane, Box)):
+            if not isinstance(scene.objects[i], Box):
                 eng.set_lightmap(i, lm)
                 ora.set_lightmap(i, lm)
     if lightmaps:
-        # generic planes have no lightmap parameterisation in the reference: both sides skip the
-        # precompute for scenes holding one, and render with empty maps (engine.rs:163-165 -> NaN -> 0)
         eng.compute_lightmaps(2)
         ora.compute_lightmaps(2)
         for i in range(eng.n_objects):
-            if not isinstance(scene.objects[i], (Plane, Box)):
+            if not isinstance(scene.objects[i], Box):  # (a box has no lightmap)
                 assert np.array_equal(eng.get_lightmap(i).view(np.uint32), ora.get_lightmap(i).view(np.uint32)), i
     hit_g, steps_g, pos_g = eng.trace_primary()
     hit_o, steps_o, pos_o = ora.trace_primary(w, h)
@@ -118,8 +116,10 @@ def _compare(scene, w=W, h=H, pose=(0, 0, (0.0, 0.0, 0.0), 0), lightmaps=True, r
 @pytest.mark.parametrize("name", sorted(SCENES))
 def test_scene_tiers(name):
     scene = SCENES[name]()
-    has_plane = any(isinstance(o, (Plane, Box)) for o in scene.objects)
-    got, ref, st, hit = _compare(scene, lightmaps=not has_plane)
+    # scenes with boxes are rendered with a fixed lightmap pattern instead of the precompute; every other
+    # scene, the one with a generic Plane included, runs the precompute on both sides first
+    has_box = any(isinstance(o, Box) for o in scene.objects)
+    got, ref, st, hit = _compare(scene, lightmaps=not has_box)
     mx, exact = assert_frames_match(got, ref, name)
     print(f"{name}: max|d|={mx} exact={exact:.5%} caps={st}")
     assert st["depth_cap_hits"] == 0
@@ -221,3 +221,47 @@ def test_capped_march_matches_oracle(scene, cap):
         assert np.array_equal(capped_frame, plain)
         assert eng.stats()["step_cap_hits"] == 0
     eng.close()
+
+
+def test_generic_plane_takes_part_in_the_lightmap_precompute():
+    """A generic Plane has a lightmap in the reference (objects.rs:216) but no way to address it
+    (objects.rs:39-42); with the parameterisation defined in include/rm.h it joins the clouds.  A Plane
+    with an axis normal in place of the red wall must reproduce the default scene's lightmaps bit for bit
+    (same sample points, same distances), and a tilted Plane must agree with the oracle."""
+    from raymarching_amd import Engine
+
+    base = default_scene()
+    ref_eng = Engine(base, 64, 64)
+    ref_eng.compute_lightmaps(4)
+    ref = np.stack([ref_eng.get_lightmap(i) for i in range(ref_eng.n_objects)])
+    ref_eng.close()
+    objs = list(base.objects)
+    objs[4] = Plane((1.0, 0.0, 0.0), -3.0, MATT, SOFT_RED)  # XPlane(-3, +1): x + 3
+    sub = Scene(objects=objs, camera_position=base.camera_position, light=base.light)
+    eng = Engine(sub, W, H)
+    eng.compute_lightmaps(4)
+    got = np.stack([eng.get_lightmap(i) for i in range(eng.n_objects)])
+    assert np.abs(got[4]).max() > 0
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    ora = make_oracle(sub)
+    ora.compute_lightmaps(4)
+    assert_frames_match(eng.render(), ora.render(W, H), "axis-normal Plane")
+    eng.close()
+    ora.close()
+    # a tilted Plane cutting off a corner of the room, seen by the camera and lit by the lamp
+    tilted = _room([Plane((-0.6, 0.0, -0.8), -2.6, MATT, SOFT_YELLOW)])
+    eng = Engine(tilted, W, H)
+    ora = make_oracle(tilted)
+    eng.compute_lightmaps(4)
+    ora.compute_lightmaps(4)
+    lit = 0
+    for i in range(eng.n_objects):
+        a, b = eng.get_lightmap(i), ora.get_lightmap(i)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), i
+        lit += int(i == 0 and np.abs(a).max() > 0)
+    assert lit == 1, "the Plane's own lightmap stayed empty"
+    hit = eng.trace_primary()[0]
+    assert (hit == 0).any(), "the Plane is not in view"
+    assert_frames_match(eng.render(), ora.render(W, H), "tilted Plane")
+    eng.close()
+    ora.close()
