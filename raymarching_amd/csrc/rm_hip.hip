@@ -78,6 +78,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderArgs 
     if (threadIdx.x == 0) diag_mem()[64] = 0;
     if (threadIdx.x < 2 + DG_SECTIONS) diag_laps()[threadIdx.x] = 0;
     if (threadIdx.x < 8) diag_kinds()[threadIdx.x] = 0;
+    if (threadIdx.x < 4) diag_lane_sums()[threadIdx.x] = 0;
     __syncthreads();
     if (threadIdx.x == 0) diag_laps()[0] = (unsigned)__builtin_readcyclecounter();
     const unsigned long long wave_t0 = wall_clock64();  // 100 MHz
@@ -137,6 +138,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderArgs 
     if (threadIdx.x < DG_SECTIONS) atomicAdd(&a.sv->stats[RM_STAT_COUNT + threadIdx.x], (unsigned long long)diag_laps()[2 + threadIdx.x]);
     if (threadIdx.x < 8) atomicAdd(&a.sv->stats[RM_STAT_COUNT + 8 + threadIdx.x], (unsigned long long)diag_kinds()[threadIdx.x]);
     if (threadIdx.x == 0) {
+        atomicAdd(&a.sv->stats[15], (unsigned long long)diag_lane_sums()[1]);  // lanes in use over march-loop iterations
+        atomicAdd(&a.sv->stats[31], (unsigned long long)diag_lane_sums()[2]);  // ... over shadow-loop iterations
         const unsigned long long now = wall_clock64(), dur = now - wave_t0;
         atomicMax(&a.sv->stats[24], dur);           // longest wave, in 10 ns ticks
         atomicAdd(&a.sv->stats[25], dur);           // summed wave lifetimes
@@ -147,6 +150,74 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderArgs 
         if (dur * 10 > 100000) atomicAdd(&a.sv->stats[30], 1ULL); // ... 100 us
     }
 #endif
+}
+
+// ---- the frame in two passes (an experiment: RM_TWO_PASS=1) -------------------------------------
+//
+// Pass 1 takes every pixel to its first hit and shades it there (engine.rs:129-194); a pixel whose
+// hit is reflective (engine.rs:231) leaves its reflection ray and what the unwinding needs - the local
+// colour, the object colour and the weight of engine.rs:239-240 - in a queue instead of following the
+// ray.  Pass 2 takes the queue in full waves: every lane follows one reflection ray to the end of its
+// chain (cast_sight_ray, one level deeper) and finishes its pixel.  Same arithmetic in the same order
+// per pixel, so the frame is the same byte for byte; what changes is which rays share a wave.
+struct ReflectQueue {
+    unsigned *count;     // entries appended so far
+    float *rec;          // [14][capacity]: ray origin, ray direction, local colour, object colour, weight; pixel offset (bits)
+    unsigned capacity;
+};
+
+template <class G>
+__global__ __launch_bounds__(BLOCK_THREADS) void render_primary_kernel(const RenderArgs a, const ReflectQueue q, const G g) {
+    int x, y_inv, out_row;
+    tile_pixel(a, x, y_inv, out_row);
+    if (x >= a.pose.W || y_inv >= a.row_end) return;
+    const SceneView &sv = *a.sv;
+    V3 dir = pixel_direction(a.pose, x, y_inv, a.screen_u, a.screen_v);
+    V3 pos = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
+    int steps;
+    bool capped;
+    const int idx = march(acc_of(g), pos, dir, -1, sv.march_cap, steps, capped, a.camera_dist, a.camera_sph);
+    if (capped) atomicAdd(&sv.stats[1], 1ULL);
+    V3 colour = v3(sv.sky[0], sv.sky[1], sv.sky[2]);
+    bool queued = false;
+    const unsigned offset = (unsigned)((size_t)out_row * a.pitch + (size_t)x * 4);
+    if (idx >= 0) {
+        const ShadeResult r = shade_local(acc_of(g), sv, idx, pos, dir);
+        colour = r.final_colour;
+        queued = r.reflectivity > 1e-3f;
+        const LaneMask want = __builtin_amdgcn_ballot_w64(queued);
+        if (want != 0) {
+            unsigned base = 0;
+            if (__builtin_amdgcn_readfirstlane(threadIdx.x) == threadIdx.x) base = atomicAdd(q.count, (unsigned)__builtin_popcountll(want));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (queued) {
+                const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+                const float fresnel = powi5(rs_clamp(1.0f - dot(r.n, -dir), 0.0f, 1.0f));
+                const V3 rv = reflect(dir, r.n);
+                const float kk = rs_clamp(fresnel + r.reflectivity, 0.0f, 1.0f);
+                const V3 rp = pos + ((rv * 3.0f) * SMALL_DISTANCE);  // engine.rs:237
+                const float vals[14] = {rp.x, rp.y, rp.z, rv.x, rv.y, rv.z, r.final_colour.x, r.final_colour.y, r.final_colour.z,
+                                        r.object_colour.x, r.object_colour.y, r.object_colour.z, kk, __uint_as_float(offset)};
+#pragma unroll
+                for (int k = 0; k < 14; k++) q.rec[(size_t)k * q.capacity + slot] = vals[k];
+            }
+        }
+    }
+    if (!queued) *reinterpret_cast<unsigned *>(a.out + offset) = pack_pixel(colour, a.pose.exposure);
+}
+
+template <class G>
+__global__ __launch_bounds__(BLOCK_THREADS) void render_reflect_kernel(const RenderArgs a, const ReflectQueue q, const G g) {
+    const SceneView &sv = *a.sv;
+    const unsigned count = *q.count;
+    for (unsigned i = blockIdx.x * BLOCK_THREADS + threadIdx.x; i < count; i += gridDim.x * BLOCK_THREADS) {
+        float v[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) v[k] = q.rec[(size_t)k * q.capacity + i];
+        const V3 rc = cast_sight_ray(acc_of(g), sv, v3(v[0], v[1], v[2]), v3(v[3], v[4], v[5]), __builtin_nanf(""), __builtin_nanf(""), 1);
+        const V3 colour = v3(v[6], v[7], v[8]) + emul(rc, v3(v[9], v[10], v[11])) * v[12];  // engine.rs:239-240
+        *reinterpret_cast<unsigned *>(a.out + __float_as_uint(v[13])) = pack_pixel(colour, a.pose.exposure);
+    }
 }
 
 // engine.rs:95-108 (disabled in the reference): four rays per pixel, half a pixel step left, right,
@@ -735,6 +806,11 @@ struct rm_engine {
     bool sample_pos_ok = false;     // false: some lightmapped type has no sample positions
     float *scratch = nullptr;  // this device's copy of the library's static scratch array
     std::vector<hipStream_t> attached_streams;  // streams of rm_group frames in flight on this engine
+    // the two-pass frame (an experiment, RM_TWO_PASS=1 when the engine is created)
+    int two_pass = 0;            // 0 off; n > 0: pass 2 runs n waves (grid-stride over the queue)
+    unsigned *d_queue_count = nullptr;
+    float *d_queue = nullptr;
+    size_t queue_capacity = 0;
 
     SceneView view() const {
         SceneView sv;
@@ -1236,6 +1312,8 @@ static void engine_free(rm_engine *e) {
     }
     if (e->xfer_stream) (void)hipStreamDestroy(e->xfer_stream);
     (void)hipFree(e->d_patch_obj);
+    (void)hipFree(e->d_queue);
+    (void)hipFree(e->d_queue_count);
     (void)hipFree(e->d_sample_pos);
     (void)hipFree(e->rad.col);
     (void)hipFree(e->rad.nrm);
@@ -1512,6 +1590,7 @@ rm_engine *rm_engine_create(const rm_scene *scene, int width, int height, int ma
         delete e;
         return nullptr;
     }
+    if (const char *v = getenv("RM_TWO_PASS")) e->two_pass = std::max(0, std::min(1 << 20, atoi(v) == 1 ? 8192 : atoi(v)));  // experiment switch
     const float zero[3] = {0.0f, 0.0f, 0.0f};
     rm_engine_input(e, 0, 0, zero, 0);
     return e;
@@ -1577,7 +1656,22 @@ int rm_engine_render_rows_device(rm_engine *e, void *d_bgra, size_t pitch_bytes,
         RM_LAUNCH(render_tree_kernel, e, grid, dim3(BLOCK_THREADS), a, e->ssaa ? 4 : 1);
     else if (e->ssaa)
         RM_LAUNCH(render_ssaa_kernel, e, grid, dim3(BLOCK_THREADS), a);
-    else
+    else if (e->two_pass > 0 && (size_t)(row_end - row_begin) * pitch_bytes < ((size_t)1 << 32)) {
+        const size_t capacity = (size_t)a.blocks_x * a.blocks_y * BLOCK_THREADS;
+        if (capacity > e->queue_capacity) {
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            (void)hipFree(e->d_queue);
+            e->d_queue = nullptr;
+            HIP_TRY(dev_alloc(&e->d_queue, capacity * 14));
+            e->queue_capacity = capacity;
+        }
+        if (!e->d_queue_count) HIP_TRY(dev_alloc(&e->d_queue_count, 1));
+        HIP_TRY(hipMemsetAsync(e->d_queue_count, 0, sizeof(unsigned), e->stream));
+        const ReflectQueue q = {e->d_queue_count, e->d_queue, (unsigned)e->queue_capacity};
+        RM_LAUNCH(render_primary_kernel, e, grid, dim3(BLOCK_THREADS), a, q);
+        const dim3 grid2((unsigned)std::min<size_t>((size_t)e->two_pass, (capacity + BLOCK_THREADS - 1) / BLOCK_THREADS));
+        RM_LAUNCH(render_reflect_kernel, e, grid2, dim3(BLOCK_THREADS), a, q);
+    } else
         RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);
     HIP_TRY(hipGetLastError());
     return RM_OK;

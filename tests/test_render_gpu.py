@@ -443,3 +443,32 @@ def test_tone_map_estimate_never_disagrees_with_the_exact_operations(gpu_engine)
     lib.orc_kat_pack_pixels(len(sample), sample.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), want.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
     _, got = gpu_engine.probe_pack(sample)
     assert np.array_equal(got, want)
+
+
+def test_two_pass_frame_is_the_same_frame(scene, oracle_lightmaps, monkeypatch):
+    """The experimental two-pass frame (RM_TWO_PASS: primary hits and local shading first, the queued
+    reflection rays in full waves afterwards) does each pixel's arithmetic in the same order: same bytes,
+    whole frame and a row range, with a pass-2 grid smaller and larger than the queue."""
+    from raymarching_amd import Engine
+
+    w, h = 640, 360
+    lm, _ = oracle_lightmaps
+
+    def frames(env):
+        if env is None:
+            monkeypatch.delenv("RM_TWO_PASS", raising=False)
+        else:
+            monkeypatch.setenv("RM_TWO_PASS", env)
+        eng = Engine(scene, w, h)
+        for i in range(eng.n_objects):
+            eng.set_lightmap(i, lm[-1][i])
+        out = [eng.render(None, 0, 0, (0.0, 0.0, 0.0), 0), eng.render(None, -300, 40, (0.2, 0.0, 0.4), 1)]
+        st = eng.stats()
+        eng.close()
+        return out, st
+
+    want, st0 = frames(None)
+    for env in ("1", "7", "100000"):
+        got, st = frames(env)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), env
+        assert st == st0
