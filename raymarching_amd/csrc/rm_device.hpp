@@ -404,60 +404,113 @@ RM_DEV CellLists grid_cell(const GridView &gv, const GridLevel &lv, V3 p) {
 //     more than k below the minimum of what was folded, so at that turn the gap is >= k in both
 //     folds, both take exactly s (<= R - 2k), and from there on they agree.  (`slack` keeps the
 //     comparison clear of the rounding of the two sums.)
+// The state of one fold over a cell's lists, kept in plain values (not captured by reference in
+// closures: the compiler then keeps it in registers instead of private memory).
+struct FoldState {
+    float r;             // the running value
+    float reach;         // r + k (hard minimum: r): a primitive at least this far away changes nothing
+    float floor_before;  // minimum of everything folded so far and of the cell's reach (blend only)
+    bool certain;        // blend only: the value is known to equal the full fold
+};
+RM_DEV FoldState fold_in(FoldState st, float s, float k, float slack, bool blend) {
+    if (blend) {
+        if (s + slack <= st.floor_before) {
+            st.r = s;
+            st.certain = true;
+        } else {
+            st.r = smooth_min(st.r, s, k);
+        }
+        st.floor_before = rs_min(st.floor_before, s);
+        st.reach = st.r + k;
+    } else {
+        st.r = rs_min(st.r, s);
+        st.reach = st.r;
+    }
+    return st;
+}
+// A primitive at least k beyond the running value (hard minimum: at or beyond it) changes nothing:
+// the smooth minimum returns the running value, which is never more than k above floor_before, so
+// neither of the other two lines of fold_in acts either.  For a sphere the squared centre distance
+// decides that for most entries, without a square root; for a box, its distance outside is at least
+// the largest of its three face distances.  The test is what most list entries cost, so it is kept
+// short: its squared distance comes from fused multiply-adds (the exact one, in the reference's order
+// of operations, is formed only for an entry that passes).
+template <class IGN>
+RM_DEV FoldState fold_sphere(FoldState st, const IGN &ign, V3 p, float cx, float cy, float cz, float rad, int oi, float k, float slack,
+                             bool blend) {
+    const V3 d = p - v3(cx, cy, cz);
+    const float m_est = __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x));  // within 2e-7 of the exact sum, relatively
+    // centre distance beyond reach + radius, compared in squares: the exact square is within 4e-7 of
+    // the true one, the rounded root within 6e-8 of the true root, the margin is 1e-5
+    const float beyond = __builtin_fmaf(rs_max(st.reach + rad, 0.0f), 1.00001f, 1e-6f);
+    if (!(m_est > beyond * beyond) && !ign.skip(oi)) st = fold_in(st, ign.mask(oi, sqrt_rn(mag_sqd(d)) - rad), k, slack, blend);
+    return st;
+}
+template <class IGN>
+RM_DEV FoldState fold_box(FoldState st, const IGN &ign, V3 p, V3 bc, V3 bh, int oi, float k, float slack, bool blend) {
+    const float face = rs_max(fabsf(p.x - bc.x) - bh.x, rs_max(fabsf(p.y - bc.y) - bh.y, fabsf(p.z - bc.z) - bh.z));
+    if (!(face > __builtin_fmaf(2e-6f, face, st.reach + 1e-6f)) && !ign.skip(oi)) st = fold_in(st, ign.mask(oi, box_sdf(bc, bh, p)), k, slack, blend);
+    return st;
+}
+
+typedef float Float16 __attribute__((ext_vector_type(16)));
+// (scalar loads need dword alignment only; the element type says so, lest a wider alignment be assumed)
+typedef Float16 __attribute__((aligned(4))) Float16u;
+typedef Int4 __attribute__((aligned(4))) Int4u;
+typedef const __attribute__((address_space(4))) Float16u *ConstFloat16s;
+typedef const __attribute__((address_space(4))) Int4u *ConstInt4us;
+
+// The sphere and box part of the fold below, done over the lists of p's grid cell only.  Returns
+// whether the value is certain to equal the fold over every sphere and box; `r` enters as the value
+// after the planes and leaves as the result.
+//
+// Every primitive missing from the lists is at least R = reach away.
+//   * Hard minimum: if the minimum over planes and listed primitives is <= R, no missing one can
+//     lower it.
+//   * Smooth minimum, folded in order: a missing primitive is a no-op whenever the running value is
+//     <= R - k at its turn, and the running value never rises.  That holds from the start if the
+//     planes already bring it there.  Otherwise the fold over the listed primitives may differ from
+//     the full one until a listed primitive with distance s arrives that lies 2k below everything
+//     folded before it (planes, listed ones, and R for the missing ones): a running value is never
+//     more than k below the minimum of what was folded, so at that turn the gap is >= k in both
+//     folds, both take exactly s (<= R - 2k), and from there on they agree.  (`slack` keeps the
+//     comparison clear of the rounding of the two sums.)
 template <class SC, class IGN>
-RM_DEV bool grid_fold(const SC &sc, const GridLevel &lv, V3 p, const IGN &ign, float &r, float k, bool blend) {
+RM_DEV bool grid_fold(const SC &sc, const GridLevel &lv, V3 p, const IGN &ign, float &r_io, float k, bool blend) {
     const GridView &gv = sc.grid();
     const CellLists c = grid_cell(gv, lv, p);
     const float R = c.reach;
-    bool certain = r <= R - k;  // blend only
-    float floor_before = rs_min(r, R);
     const float slack = 2.01f * k + 1e-4f;
-    auto fold = [&](float s) {
-        if (blend) {
-            if (s + slack <= floor_before) {
-                r = s;
-                certain = true;
-            } else {
-                r = smooth_min(r, s, k);
-            }
-            floor_before = rs_min(floor_before, s);
-        } else {
-            r = rs_min(r, s);
-        }
-    };
-    // A primitive at least k beyond the running value (hard minimum: at or beyond it) changes nothing:
-    // the smooth minimum returns the running value, which is never more than k above floor_before, so
-    // neither of the other two lines of `fold` acts either.  For a sphere the squared centre distance
-    // decides that for most entries, without a square root; for a box, its distance outside is at least
-    // the largest of its three face distances.
-    auto sphere_entry = [&](float cx, float cy, float cz, float rad, int oi) {
-        const float m = mag_sqd(p - v3(cx, cy, cz));
-        // centre distance beyond (running value [+ k]) + radius, compared in squares: `m` is within
-        // 4e-7 of the true square, the rounded root within 6e-8 of the true root, the margin is 1e-5
-        const float beyond = rs_max((blend ? r + k : r) + rad, 0.0f) * 1.00001f + 1e-6f;
-        if (!(m > beyond * beyond) && !ign.skip(oi)) fold(ign.mask(oi, sqrt_rn(m) - rad));
-    };
-    auto box_entry = [&](V3 bc, V3 bh, int oi) {
-        const float face = rs_max(fabsf(p.x - bc.x) - bh.x, rs_max(fabsf(p.y - bc.y) - bh.y, fabsf(p.z - bc.z) - bh.z));
-        if (!(face > (blend ? r + k : r) + 2e-6f * face + 1e-6f) && !ign.skip(oi)) fold(ign.mask(oi, box_sdf(bc, bh, p)));
-    };
+    FoldState st;
+    st.r = r_io;
+    st.reach = blend ? r_io + k : r_io;
+    st.certain = r_io <= R - k;  // blend only
+    st.floor_before = rs_min(r_io, R);
     const ConstFloat4s sph_geom = (ConstFloat4s)lv.sph_geom, box_geom = (ConstFloat4s)lv.box_geom;
     const ConstInts sph_index = constant(lv.sph_index), box_index = constant(lv.box_index);
     // The pixels of a tile mostly sit in one cell.  A wave whose lanes all do walks the lists with
     // wave-uniform indices: the entries arrive by scalar loads, once per wave, and no lane waits for
-    // another's longer list.
+    // another's longer list.  Four spheres (two boxes) come with one 64-byte load, so that the wave
+    // waits for memory once per group and not once per entry (the arrays are padded by one group).
     const int us0 = __builtin_amdgcn_readfirstlane(c.s0), us1 = __builtin_amdgcn_readfirstlane(c.s1);
     const int ub0 = __builtin_amdgcn_readfirstlane(c.b0), ub1 = __builtin_amdgcn_readfirstlane(c.b1);
     if (wave_all(c.s0 == us0 && c.s1 == us1 && c.b0 == ub0 && c.b1 == ub1)) {
-        for (int e = us0; e < us1; e++) {
-            const Float4 g = sph_geom[e];
-            sphere_entry(g.x, g.y, g.z, g.w, sph_index[e]);
+        for (int e = us0; e < us1; e += 4) {
+            const Float16 g = *(ConstFloat16s)(constant(lv.sph_geom) + 4 * e);
+            const Int4 oi = *(ConstInt4us)(sph_index + e);
+            st = fold_sphere(st, ign, p, g.s0, g.s1, g.s2, g.s3, oi.x, k, slack, blend);
+            if (e + 1 < us1) st = fold_sphere(st, ign, p, g.s4, g.s5, g.s6, g.s7, oi.y, k, slack, blend);
+            if (e + 2 < us1) st = fold_sphere(st, ign, p, g.s8, g.s9, g.sa, g.sb, oi.z, k, slack, blend);
+            if (e + 3 < us1) st = fold_sphere(st, ign, p, g.sc, g.sd, g.se, g.sf, oi.w, k, slack, blend);
         }
-        for (int e = ub0; e < ub1; e++) {
-            const Float4 g0 = box_geom[2 * e], g1 = box_geom[2 * e + 1];
-            box_entry(v3(g0.x, g0.y, g0.z), v3(g0.w, g1.x, g1.y), box_index[e]);
+        for (int e = ub0; e < ub1; e += 2) {
+            const Float16 g = *(ConstFloat16s)(constant(lv.box_geom) + 8 * e);
+            const int o0 = box_index[e], o1 = box_index[e + 1];
+            st = fold_box(st, ign, p, v3(g.s0, g.s1, g.s2), v3(g.s3, g.s4, g.s5), o0, k, slack, blend);
+            if (e + 1 < ub1) st = fold_box(st, ign, p, v3(g.s8, g.s9, g.sa), v3(g.sb, g.sc, g.sd), o1, k, slack, blend);
         }
-        return blend ? certain : (r <= R);
+        r_io = st.r;
+        return blend ? st.certain : (st.r <= R);
     }
     // Otherwise every lane walks its own lists.  Entries are fetched four (boxes: two) at a time
     // before any is used, so that a list costs one memory round trip per group instead of one per
@@ -473,7 +526,7 @@ RM_DEV bool grid_fold(const SC &sc, const GridLevel &lv, V3 p, const IGN &ign, f
         }
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (e + u < c.s1) sphere_entry(g[u].x, g[u].y, g[u].z, g[u].w, oi[u]);
+            if (e + u < c.s1) st = fold_sphere(st, ign, p, g[u].x, g[u].y, g[u].z, g[u].w, oi[u], k, slack, blend);
     }
     for (int e = c.b0; e < c.b1; e += 2) {
         Float4 g0[2], g1[2];
@@ -487,9 +540,10 @@ RM_DEV bool grid_fold(const SC &sc, const GridLevel &lv, V3 p, const IGN &ign, f
         }
 #pragma unroll
         for (int u = 0; u < 2; u++)
-            if (e + u < c.b1) box_entry(v3(g0[u].x, g0[u].y, g0[u].z), v3(g0[u].w, g1[u].x, g1[u].y), oi[u]);
+            if (e + u < c.b1) st = fold_box(st, ign, p, v3(g0[u].x, g0[u].y, g0[u].z), v3(g0[u].w, g1[u].x, g1[u].y), oi[u], k, slack, blend);
     }
-    return blend ? certain : (r <= R);
+    r_io = st.r;
+    return blend ? st.certain : (st.r <= R);
 }
 
 // The value `distance` holds after the object loop of ray.rs:23-33 / 98-107: the minimum over
@@ -542,6 +596,7 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, LaneMask act, SphereB
 #pragma nounroll
             for (int level = 0; level < kGridLevels; level++) {
                 float r = d;
+                if (level > 0) diag_event(0);  // the short lists left the value open
                 if (grid_fold(sc, sc.grid().level[level], p, ign, r, k, blend)) return r;
             }
             diag_event(7);

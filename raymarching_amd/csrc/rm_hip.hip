@@ -66,8 +66,21 @@ __device__ __forceinline__ void tile_pixel(const RenderArgs &a, int &x, int &y_i
 }
 
 // engine.rs:77-126 fused: direction, cast_sight_ray, tone map, pack.
+// Waves per SIMD the compiler must make room for (second launch bound).  The large-scene kernel walks
+// lists in memory and waits for them: it is bound by latency, not by instruction issue, and runs
+// 20 % faster with 8 waves per SIMD and 40 of its values in private memory than with the 4 waves its
+// 102 registers would allow.  The small tiers keep their scene in scalar registers and are bound by
+// instruction issue: the compiler's own choice (72 registers, 7 waves) is left alone.
 template <class G>
-__global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderArgs a, const G g) {
+struct MinWaves {
+    static constexpr int value = 1;
+};
+template <>
+struct MinWaves<GroupedLarge> {
+    static constexpr int value = 8;
+};
+template <class G>
+__global__ __launch_bounds__(BLOCK_THREADS, MinWaves<G>::value) void render_kernel(const RenderArgs a, const G g) {
     int x, y_inv, out_row;
 #ifdef RM_DIAG_TIME
     const unsigned long long diag_t0 = wall_clock64();
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_reflect_kernel(const Ren
 // engine.rs:95-108 (disabled in the reference): four rays per pixel, half a pixel step left, right,
 // up and down of the pixel's direction before normalising, averaged in that order.
 template <class G>
-__global__ __launch_bounds__(BLOCK_THREADS) void render_ssaa_kernel(const RenderArgs a, const G g) {
+__global__ __launch_bounds__(BLOCK_THREADS, MinWaves<G>::value) void render_ssaa_kernel(const RenderArgs a, const G g) {
     int x, y_inv, out_row;
     tile_pixel(a, x, y_inv, out_row);
     if (x >= a.pose.W || y_inv >= a.row_end) return;
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_ssaa_kernel(const Render
 // supersampling of engine.rs:95-108.  A kernel of its own: the tree walk needs more registers and
 // private memory than the plain frame should pay for.
 template <class G>
-__global__ __launch_bounds__(BLOCK_THREADS) void render_tree_kernel(const RenderArgs a, int samples, const G g) {
+__global__ __launch_bounds__(BLOCK_THREADS, MinWaves<G>::value) void render_tree_kernel(const RenderArgs a, int samples, const G g) {
     int x, y_inv, out_row;
     tile_pixel(a, x, y_inv, out_row);
     if (x >= a.pose.W || y_inv >= a.row_end) return;
@@ -1210,12 +1223,17 @@ static int engine_upload(rm_engine *e) {
                         cell_rec[4 * c + 2] = (lv[L].s_start[c + 1] - lv[L].s_start[c]) | ((lv[L].b_start[c + 1] - lv[L].b_start[c]) << 16);
                         memcpy(&cell_rec[4 * c + 3], &lv[L].cell_reach[c], sizeof(float));
                     }
+                    e->grid_entries += lv[L].s_index.size() + lv[L].b_index.size();
+                    // the kernels fetch a wave-uniform list four spheres (two boxes) at a time: one group of padding
+                    lv[L].s_geom.resize(lv[L].s_geom.size() + 4 * 4, 0.0f);
+                    lv[L].s_index.resize(lv[L].s_index.size() + 4, -1);
+                    lv[L].b_geom.resize(lv[L].b_geom.size() + 2 * 8, 0.0f);
+                    lv[L].b_index.resize(lv[L].b_index.size() + 2, -1);
                     HIP_TRY(up_i(cell_rec, &gv.level[L].cell));
                     HIP_TRY(up_f(lv[L].s_geom, &gv.level[L].sph_geom));
                     HIP_TRY(up_i(lv[L].s_index, &gv.level[L].sph_index));
                     HIP_TRY(up_f(lv[L].b_geom, &gv.level[L].box_geom));
                     HIP_TRY(up_i(lv[L].b_index, &gv.level[L].box_index));
-                    e->grid_entries += lv[L].s_index.size() + lv[L].b_index.size();
                     if (getenv("RM_VERBOSE")) {
                         int longest_list = 0;
                         for (int c = 0; c < gv.cells; c++)

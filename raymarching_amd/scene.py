@@ -246,12 +246,27 @@ def stress_scene(n_spheres: int = 250, seed: int = 0xC0FFEE, texture_path: Optio
         r = float(rng.uniform(0.05, 0.4))
         if all(np.linalg.norm(c - pc) > r + pr + 0.02 for pc, pr in placed):
             placed.append((c, r))
+    # A reflection ray starts 3e-3 off the surface (engine.rs:237).  Inside the blend zone of a smooth
+    # union that is still "on" the surface, so the ray hits its own object again and the recursion runs
+    # hundreds deep.  In a blended scene only primitives that stand clear of every blend zone keep their
+    # reflective material: everything else (primitives and walls) at least 2k + 0.01 away from them, so
+    # that the ordered fold returns their own distance unchanged all around their surface (a running
+    # value is never more than k below what was folded before).
+    centres = np.array([c for c, _ in placed])
+    radii = np.array([r for _, r in placed])
+    if len(placed):
+        gaps = np.linalg.norm(centres[:, None] - centres[None], axis=-1) - radii[:, None] - radii[None]
+        np.fill_diagonal(gaps, np.inf)
+        walls = np.minimum.reduce([centres[:, 0] + 3.0, 3.0 - centres[:, 0], centres[:, 1] + 2.0, 4.0 - centres[:, 1],
+                                   centres[:, 2] + 4.0, 2.0 - centres[:, 2]]) - radii
+        clear = np.minimum(gaps.min(axis=1), walls) >= 2.0 * smooth_union + 0.01
     for i, (c, r) in enumerate(placed):
         kind = i % 4
-        # A reflection ray starts 3e-3 off the surface (engine.rs:237).  Inside the blend zone of a
-        # smooth union that is still "on" the surface, so the ray hits its own object again and the
-        # recursion runs hundreds deep.  Blended scenes therefore get no reflective materials.
-        refl = 0.0 if smooth_union > 0.0 else 1.0
+        is_box = boxes and i % 3 == 2
+        # (and no box among them: a reflection ray that grazes a flat face starts less than SMALL_DISTANCE
+        # above it, hits the face again 3e-3 further on, and so crawls along the whole face, one level of
+        # recursion per step - a hundred levels on these boxes)
+        refl = 1.0 if (smooth_union <= 0.0 or (clear[i] and not is_box)) else 0.0
         if kind == 0:
             mat = Material(0.05, 0.3, 0.2, 16.0, 0.5 * refl, 0.0)  # half mirror
         elif kind == 1:

@@ -45,6 +45,7 @@ kinds = ["", "march-loop iterations", "shadow-loop iterations", "  of both: with
          "steps through the spatial index", "  of them: settled by a full walk"]
 for k in range(1, len(kinds)):
     print(f"  {kinds[k]:46s} {raw[16 + k] / waves:7.2f} per wave")
+print(f"  {'  of them: the short lists left the value open':46s} {raw[16] / waves:7.2f} per wave")
 print(f"  lanes in use per march-loop iteration {raw[15] / max(raw[17], 1):.1f} of 64, per shadow-loop iteration {raw[31] / max(raw[18], 1):.1f} of 64")
 print(f"  longest wave {raw[24] / 100:.1f} us, mean wave {raw[25] / waves / 100:.2f} us, grid span {(raw[27] - ((~raw[26]) & 0xFFFFFFFFFFFFFFFF)) / 100:.1f} us")
 print(f"  waves longer than 20 us: {raw[28]}, 50 us: {raw[29]}, 100 us: {raw[30]}")
