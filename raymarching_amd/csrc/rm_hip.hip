@@ -465,17 +465,21 @@ __global__ void rad_form_kernel(const RadArgs a, int p0, int p1, int j0, const G
 // radiosity.rs:107-156 + 184-192 for 64 receivers per workgroup: the ordered sums over sources.
 // The additions of one receiver and channel must run in source order (f32 addition does not
 // associate), but fetching the form factors need not: all 256 threads stream a slab of FT
-// (kBounceChunk sources x 64 receivers, receiver-contiguous rows) and the matching emissive
+// (CHUNK sources x 64 receivers, receiver-contiguous rows) and the matching emissive
 // values into LDS with many loads in flight, then three waves - one per colour channel - fold the
 // slab in order, one receiver per lane, and the next slab follows.  A pair that contributes nothing
 // (form factor -1) enters the slab as 0: its term emission * 0 is +0 (emission values are finite and
 // not negative), which leaves a sum that started at +0 unchanged bit for bit.
-constexpr int kBounceChunk = 64;  // 64 x 64 floats of FT + 64 x 3 emissive floats: 17 KiB of LDS, eight workgroups per CU
+// The slab depth CHUNK (sources per slab) sets how many bytes a workgroup keeps in flight: 64 sources
+// are 16 KiB, enough once eight workgroups share a compute unit; with fewer workgroups (smaller
+// lightmaps) deeper slabs keep the memory system as busy.  The order of the additions does not depend
+// on it.
+template <int CHUNK>
 __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0, int p1) {
-    __shared__ float slab[kBounceChunk][64];
-    __shared__ float em_s[kBounceChunk * 3];
-    constexpr int kPerThread = kBounceChunk / 4;  // rows of a slab each thread fetches
-    static_assert(kBounceChunk * 3 <= 256, "one emissive value per thread");
+    __shared__ float slab[CHUNK][64];
+    __shared__ float em_s[CHUNK * 3];
+    constexpr int kPerThread = CHUNK / 4;             // rows of a slab each thread fetches
+    constexpr int kEmPerThread = (CHUNK * 3 + 255) / 256;  // emissive values of a slab each thread fetches
     const int NP = a.n_patches;
     const int i0 = p0 + blockIdx.x * 64;
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;  // part: row phase when loading, channel when summing
@@ -484,28 +488,48 @@ __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0
     // The next slab travels from memory into registers while the current one is folded, so a fold
     // waits for memory only once, at the first slab (with few workgroups in flight - 8 for the 512
     // patches of the default scene - nothing else would hide that wait).
-    float pre[kPerThread], em_pre;
+    float pre[kPerThread], em_pre[kEmPerThread];
+    // Every load of a fetch is issued unconditionally, at an address clamped into the arrays: a load
+    // under a condition becomes a branch with a wait behind it, and the fetches of a slab would go to
+    // memory one after the other.  What a clamped load brought is discarded when the slab is stored.
+    const int ic = min(i, NP - 1);
     const auto fetch = [&](int j0) {
-        const int rows = min(kBounceChunk, NP - j0);
 #pragma unroll
-        for (int k = 0; k < kPerThread; k++) {
-            const int jj = part + 4 * k;
-            const float f = (valid && jj < rows) ? a.ft[(size_t)(j0 + jj) * NP + i] : 0.0f;
-            pre[k] = f == -1.0f ? 0.0f : f;  // a pair that contributes nothing: emission * 0 = +0
-        }
-        em_pre = (int)threadIdx.x < rows * 3 ? a.emissive[3 * j0 + threadIdx.x] : 0.0f;
+        for (int k = 0; k < kPerThread; k++) pre[k] = a.ft[(size_t)min(j0 + part + 4 * k, NP - 1) * NP + ic];
+#pragma unroll
+        for (int k = 0; k < kEmPerThread; k++) em_pre[k] = a.emissive[min(3 * j0 + (int)threadIdx.x + 256 * k, 3 * NP - 1)];
     };
     fetch(0);
     float acc = 0.0f;
-    for (int j0 = 0; j0 < NP; j0 += kBounceChunk) {
-        const int rows = min(kBounceChunk, NP - j0);
+    for (int j0 = 0; j0 < NP; j0 += CHUNK) {
+        const int rows = min(CHUNK, NP - j0);
 #pragma unroll
-        for (int k = 0; k < kPerThread; k++) slab[part + 4 * k][lane] = pre[k];
-        if (threadIdx.x < kBounceChunk * 3) em_s[threadIdx.x] = em_pre;
+        for (int k = 0; k < kPerThread; k++) {
+            // a pair that contributes nothing (-1), a row beyond the last source, a receiver beyond p1: emission * 0 = +0
+            const bool counts = valid && part + 4 * k < rows && !(pre[k] == -1.0f);
+            slab[part + 4 * k][lane] = counts ? pre[k] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < kEmPerThread; k++) {
+            const int t = (int)threadIdx.x + 256 * k;
+            if (t < CHUNK * 3) em_s[t] = t < rows * 3 ? em_pre[k] : 0.0f;
+        }
         __syncthreads();
-        if (j0 + kBounceChunk < NP) fetch(j0 + kBounceChunk);
+        if (j0 + CHUNK < NP) fetch(j0 + CHUNK);
         if (part < 3 && valid) {
-            for (int jj = 0; jj < rows; jj++) acc = acc + em_s[3 * jj + part] * slab[jj][lane];
+            // The additions form one dependent chain per receiver and channel; everything else of a
+            // step - the two reads from the slab and the product - does not depend on the sum so far.
+            // Sixteen steps at a time: their operands are fetched and multiplied first, then added in
+            // source order, so that a step costs one addition's latency and not a round trip to LDS.
+            int jj = 0;
+            for (; jj + 16 <= rows; jj += 16) {
+                float term[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) term[u] = em_s[3 * (jj + u) + part] * slab[jj + u][lane];
+#pragma unroll
+                for (int u = 0; u < 16; u++) acc = acc + term[u];
+            }
+            for (; jj < rows; jj++) acc = acc + em_s[3 * jj + part] * slab[jj][lane];
         }
         __syncthreads();
     }
@@ -2003,7 +2027,17 @@ static int rad_bounce_on(rm_engine *e, const RadBuffers &b, int p0, int p1) {
     if (p0 == p1) return RM_OK;
     RadArgs a = e->rad_args(b);
     dim3 grid((p1 - p0 + 63) / 64);
-    hipLaunchKernelGGL(rad_bounce_kernel, grid, dim3(256), 0, e->stream, a, p0, p1);
+    // fewer than eight workgroups per compute unit: deeper slabs, so that as many bytes stay in flight
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
+    int chunk = 128;
+    if (const char *c = getenv("RM_BOUNCE_CHUNK")) chunk = atoi(c);  // tuning aid
+    if (chunk == 64)
+        hipLaunchKernelGGL(rad_bounce_kernel<64>, grid, dim3(256), 0, e->stream, a, p0, p1);
+    else if (chunk == 192)
+        hipLaunchKernelGGL(rad_bounce_kernel<192>, grid, dim3(256), 0, e->stream, a, p0, p1);
+    else
+        hipLaunchKernelGGL(rad_bounce_kernel<128>, grid, dim3(256), 0, e->stream, a, p0, p1);
     HIP_TRY(hipGetLastError());
     return RM_OK;
 }
