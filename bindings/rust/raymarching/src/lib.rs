@@ -61,6 +61,59 @@ fn check(rc: i32) -> Result<(), Error> {
     }
 }
 
+/// `construct_objects()` and the `Engine { .. }` literal (main.rs:64-71,154-193) as an rm_scene; the
+/// caller destroys it.
+unsafe fn build_scene(objects: &[Object], camera_position: Vec3, light: &PointLight) -> Result<*mut sys::rm_scene, Error> {
+    let scene = sys::rm_scene_create();
+    if scene.is_null() {
+        return Err(last_error());
+    }
+    let mut registered: Vec<(*const Texture, i32)> = Vec::new();
+    let mut result = Ok(());
+    for o in objects {
+        let rc = match o {
+            Object::Sphere { position, radius, material, colour } =>
+                sys::rm_scene_add_sphere(scene, position.as_ptr(), *radius, material, colour.as_ptr()),
+            Object::Plane { normal, distance, material, colour } =>
+                sys::rm_scene_add_plane(scene, normal.as_ptr(), *distance, material, colour.as_ptr()),
+            Object::XPlane { x, dir, material, colour } =>
+                sys::rm_scene_add_xplane(scene, *x, *dir, material, colour.as_ptr()),
+            Object::ZPlane { z, dir, material, colour } =>
+                sys::rm_scene_add_zplane(scene, *z, *dir, material, colour.as_ptr()),
+            Object::Box { position, half_extent, material, colour } =>
+                sys::rm_scene_add_box(scene, position.as_ptr(), half_extent.as_ptr(), material, colour.as_ptr()),
+            Object::YPlane { y, dir, material, colour, texture } => {
+                let key = *texture as *const Texture;
+                let id = match registered.iter().find(|(p, _)| *p == key) {
+                    Some((_, id)) => *id,
+                    None => {
+                        let id = sys::rm_texture_create_rgb8(scene, texture.rgb8.as_ptr(), texture.width,
+                                                             texture.height, texture.uscale, texture.vscale);
+                        registered.push((key, id));
+                        id
+                    }
+                };
+                if id < 0 { id } else { sys::rm_scene_add_yplane(scene, *y, *dir, material, colour.as_ptr(), id) }
+            }
+        };
+        if rc < 0 {
+            result = Err(last_error());
+            break;
+        }
+    }
+    if result.is_ok() {
+        result = check(sys::rm_scene_set_light(scene, light.position.as_ptr(), light.intensity))
+            .and_then(|_| check(sys::rm_scene_set_camera(scene, camera_position.as_ptr())));
+    }
+    match result {
+        Ok(()) => Ok(scene),
+        Err(e) => {
+            sys::rm_scene_destroy(scene);
+            Err(e)
+        }
+    }
+}
+
 /// engine.rs:329-333; width and height are run-time values here.
 pub struct Engine {
     handle: *mut sys::rm_engine,
@@ -72,54 +125,9 @@ impl Engine {
     pub fn new(objects: &[Object], camera_position: Vec3, light: &PointLight, width: usize, height: usize,
                map_size: usize, device: i32) -> Result<Engine, Error> {
         unsafe {
-            let scene = sys::rm_scene_create();
-            if scene.is_null() {
-                return Err(last_error());
-            }
-            let mut registered: Vec<(*const Texture, i32)> = Vec::new();
-            let mut result = Ok(());
-            for o in objects {
-                let rc = match o {
-                    Object::Sphere { position, radius, material, colour } =>
-                        sys::rm_scene_add_sphere(scene, position.as_ptr(), *radius, material, colour.as_ptr()),
-                    Object::Plane { normal, distance, material, colour } =>
-                        sys::rm_scene_add_plane(scene, normal.as_ptr(), *distance, material, colour.as_ptr()),
-                    Object::XPlane { x, dir, material, colour } =>
-                        sys::rm_scene_add_xplane(scene, *x, *dir, material, colour.as_ptr()),
-                    Object::ZPlane { z, dir, material, colour } =>
-                        sys::rm_scene_add_zplane(scene, *z, *dir, material, colour.as_ptr()),
-                    Object::Box { position, half_extent, material, colour } =>
-                        sys::rm_scene_add_box(scene, position.as_ptr(), half_extent.as_ptr(), material, colour.as_ptr()),
-                    Object::YPlane { y, dir, material, colour, texture } => {
-                        let key = *texture as *const Texture;
-                        let id = match registered.iter().find(|(p, _)| *p == key) {
-                            Some((_, id)) => *id,
-                            None => {
-                                let id = sys::rm_texture_create_rgb8(scene, texture.rgb8.as_ptr(), texture.width,
-                                                                     texture.height, texture.uscale, texture.vscale);
-                                registered.push((key, id));
-                                id
-                            }
-                        };
-                        if id < 0 { id } else { sys::rm_scene_add_yplane(scene, *y, *dir, material, colour.as_ptr(), id) }
-                    }
-                };
-                if rc < 0 {
-                    result = Err(last_error());
-                    break;
-                }
-            }
-            if result.is_ok() {
-                result = check(sys::rm_scene_set_light(scene, light.position.as_ptr(), light.intensity))
-                    .and_then(|_| check(sys::rm_scene_set_camera(scene, camera_position.as_ptr())));
-            }
-            let handle = if result.is_ok() {
-                sys::rm_engine_create(scene, width as i32, height as i32, map_size as i32, device)
-            } else {
-                std::ptr::null_mut()
-            };
+            let scene = build_scene(objects, camera_position, light)?;
+            let handle = sys::rm_engine_create(scene, width as i32, height as i32, map_size as i32, device);
             sys::rm_scene_destroy(scene);
-            result?;
             if handle.is_null() {
                 return Err(last_error());
             }
@@ -130,6 +138,21 @@ impl Engine {
     /// engine.rs:246 (the reference runs four bounces)
     pub fn compute_lightmaps(&mut self) -> Result<(), Error> {
         check(unsafe { sys::rm_engine_compute_lightmaps(self.handle, 4) })
+    }
+
+    /// The same without any device allocation (work buffers in the library's static array; at most
+    /// `rm_sys::RM_STATIC_MAX_PATCHES` patches).
+    pub fn compute_lightmaps_static(&mut self) -> Result<(), Error> {
+        check(unsafe { sys::rm_engine_compute_lightmaps_static(self.handle, 4) })
+    }
+
+    /// All lightmaps to / from one file, to skip the precompute at the next start (the reference
+    /// recomputes at every start, main.rs:73).
+    pub fn save_lightmaps(&mut self, path: &std::ffi::CStr) -> Result<(), Error> {
+        check(unsafe { sys::rm_engine_save_lightmaps(self.handle, path.as_ptr()) })
+    }
+    pub fn load_lightmaps(&mut self, path: &std::ffi::CStr) -> Result<(), Error> {
+        check(unsafe { sys::rm_engine_load_lightmaps(self.handle, path.as_ptr()) })
     }
 
     /// engine.rs:38-41; `buffer` holds `height` rows of `pitch` bytes, B,G,R,0 per pixel.
@@ -163,5 +186,48 @@ impl Engine {
 impl Drop for Engine {
     fn drop(&mut self) {
         unsafe { sys::rm_engine_destroy(self.handle) }
+    }
+}
+
+/// The same engine over several GPUs of this process (rm_multi_*): GPU i of n renders every n-th strip
+/// of 8 rows and copies it into the caller's frame over its own PCIe link; the lightmap patches are
+/// split likewise.  What the reference's main loop needs is unchanged: `compute_lightmaps()` once
+/// (main.rs:73), `render(buffer, ..)` per frame (main.rs:141-145).
+pub struct MultiEngine {
+    handle: *mut sys::rm_multi,
+    pub width: usize,
+    pub height: usize,
+}
+
+impl MultiEngine {
+    pub fn new(objects: &[Object], camera_position: Vec3, light: &PointLight, width: usize, height: usize,
+               map_size: usize, devices: &[i32]) -> Result<MultiEngine, Error> {
+        unsafe {
+            let scene = build_scene(objects, camera_position, light)?;
+            let handle = sys::rm_multi_create(scene, width as i32, height as i32, map_size as i32, devices.as_ptr(), devices.len() as i32);
+            sys::rm_scene_destroy(scene);
+            if handle.is_null() {
+                return Err(last_error());
+            }
+            Ok(MultiEngine { handle, width, height })
+        }
+    }
+
+    pub fn compute_lightmaps(&mut self) -> Result<(), Error> {
+        check(unsafe { sys::rm_multi_compute_lightmaps(self.handle, 4) })
+    }
+
+    pub fn render(&mut self, buffer: &mut [u8], pitch: usize, mouse_x: i32, mouse_y: i32, rel_move: Vec3,
+                  scroll: i32) -> Result<(), Error> {
+        assert!(pitch >= self.width * 4 && buffer.len() >= pitch * self.height);
+        check(unsafe {
+            sys::rm_multi_render(self.handle, buffer.as_mut_ptr(), pitch, mouse_x, mouse_y, rel_move.as_ptr(), scroll)
+        })
+    }
+}
+
+impl Drop for MultiEngine {
+    fn drop(&mut self) {
+        unsafe { sys::rm_multi_destroy(self.handle) }
     }
 }

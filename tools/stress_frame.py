@@ -11,15 +11,16 @@ from raymarching_amd import _lib
 if os.environ.get("RM_LIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["RM_LIB"])
 from raymarching_amd.engine import Engine
-from raymarching_amd.scene import Box, stress_scene
+from raymarching_amd.scene import Box, stress_lightmap_pattern, stress_scene
 
-W, H = int(os.environ.get("RM_W", 1920)), int(os.environ.get("RM_H", 1080))
+W, H = int(os.environ.get("RM_W", 7680)), int(os.environ.get("RM_H", 4320))  # bench.py --workload stress
 scene = stress_scene(250, boxes=True, smooth_union=float(os.environ.get("RM_STRESS_K", "0.08")))
 eng = Engine(scene, W, H)
-lm = np.full((8, 8, 3), 0.1, dtype=np.float32)
+lm = stress_lightmap_pattern()
 for i, obj in enumerate(scene.objects):
     if not isinstance(obj, Box):
         eng.set_lightmap(i, lm)
+eng.set_march_cap(1024)
 eng.input(0, 0, (0, 0, 0), 0)
 buf = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
 for _ in range(int(os.environ.get("RM_FRAMES", 3))):
