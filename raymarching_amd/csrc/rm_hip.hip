@@ -68,16 +68,17 @@ __device__ __forceinline__ void tile_pixel(const RenderArgs &a, int &x, int &y_i
 // engine.rs:77-126 fused: direction, cast_sight_ray, tone map, pack.
 // Waves per SIMD the compiler must make room for (second launch bound).  The large-scene kernel walks
 // lists in memory and waits for them: it is bound by latency, not by instruction issue, and runs
-// 20 % faster with 8 waves per SIMD and 40 of its values in private memory than with the 4 waves its
-// 102 registers would allow.  The small tiers keep their scene in scalar registers and are bound by
-// instruction issue: the compiler's own choice (72 registers, 7 waves) is left alone.
+// 20 % faster with 7 waves per SIMD and 21 of its values in private memory than with the 4 waves its
+// 102 registers would allow (8 waves: the same time with twice the values spilled).  The small tiers
+// keep their scene in scalar registers and are bound by instruction issue: the compiler's own choice
+// (72 registers, 7 waves) is left alone.
 template <class G>
 struct MinWaves {
     static constexpr int value = 1;
 };
 template <>
 struct MinWaves<GroupedLarge> {
-    static constexpr int value = 8;
+    static constexpr int value = 7;
 };
 template <class G>
 __global__ __launch_bounds__(BLOCK_THREADS, MinWaves<G>::value) void render_kernel(const RenderArgs a, const G g) {
