@@ -521,7 +521,10 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic: the reference's default scene (main.rs:154-193), first-frame pose, lightmaps from 4 radiosity bounces",
+            "data": ("synthetic: the reference's default scene (main.rs:154-193), first-frame pose, lightmaps from 4 radiosity bounces"
+                     if args.workload == "render" else
+                     "synthetic: seed-fixed stress scene (raymarching_amd.scene.stress_scene: 167 spheres and 83 boxes in the reference's room, "
+                     "15 of the spheres reflective), first-frame pose, a fixed lightmap pattern"),
             "config": {
                 "workload": (f"default scene {W}x{H}, march + shading + texture + lightmap + reflections" if args.workload == "render"
                              else f"stress scene: 250 spheres and boxes + room, smooth union k=0.08, {W}x{H}, march cap 1024")
