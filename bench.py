@@ -356,17 +356,11 @@ def main():
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
     if args.workload == "stress":
-        # boxes have no lightmap parameterisation: a fixed smooth pattern stands in for the precompute
-        from raymarching_amd.scene import Box, stress_lightmap_pattern
-
-        lm = stress_lightmap_pattern()
-
-        for i, obj in enumerate(scene.objects):
-            if not isinstance(obj, Box):
-                eng.set_lightmap(i, lm)
         eng.set_march_cap(1024)
-    else:
-        eng.compute_lightmaps(4)  # main.rs:73: once, before the frame loop (not timed)
+    if not gathering:
+        # main.rs:73: once, before the frame loop (not timed).  On the stress scene the 173 spheres and
+        # planes carry the 11072 patches; boxes occlude and receive nothing.
+        eng.compute_lightmaps(4)
     eng.input(0, 0, (0.0, 0.0, 0.0), 0)  # first-frame pose (main.rs:78-80,122)
     if args.ssaa:
         eng.set_ssaa(4)
@@ -408,8 +402,7 @@ def main():
                 return 0
 
             group = Group(eng, rank, world, frames_in_flight=in_flight, all_gather=host_all_gather)
-        if args.workload != "stress":
-            group.compute_lightmaps(4)  # the same precompute, patch-sharded (a rehearsal of that exchange too)
+        group.compute_lightmaps(4)  # the same precompute, patch-sharded (a rehearsal of that exchange too)
         info = group.info()
         strips_per_rank, wire = info["strips_per_rank"], info["bytes_per_pixel_exchanged"]
         my_rows = sum(min(STRIP_ROWS, H - (rank + k * world) * STRIP_ROWS) for k in range(strips_per_rank) if (rank + k * world) * STRIP_ROWS < H)
@@ -524,7 +517,7 @@ def main():
             "data": ("synthetic: the reference's default scene (main.rs:154-193), first-frame pose, lightmaps from 4 radiosity bounces"
                      if args.workload == "render" else
                      "synthetic: seed-fixed stress scene (raymarching_amd.scene.stress_scene: 167 spheres and 83 boxes in the reference's room, "
-                     "15 of the spheres reflective), first-frame pose, a fixed lightmap pattern"),
+                     "15 of the spheres reflective), first-frame pose, lightmaps from 4 radiosity bounces over its 11072 patches"),
             "config": {
                 "workload": (f"default scene {W}x{H}, march + shading + texture + lightmap + reflections" if args.workload == "render"
                              else f"stress scene: 250 spheres and boxes + room, smooth union k=0.08, {W}x{H}, march cap 1024")

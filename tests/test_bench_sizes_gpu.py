@@ -74,7 +74,10 @@ def test_1080p_render_then_fxaa_chain(scene, oracle_lightmaps):
 def test_stress_frame_rows_at_7680x4320():
     """Config "256 mixed primitives with smooth unions, 7680x4320, march cap 1024": eight rows spread
     over the frame against the oracle's full fold over all primitives, no march cut by the cap, and
-    the whole frame bit-stable from run to run."""
+    the whole frame bit-stable from run to run.  Four of the rows are rendered from the lightmaps of
+    the library's own precompute on this scene (11072 patches: hours for the oracle, whose parity on
+    the precompute is pinned on the smaller scenes; here the oracle renders from the same values),
+    four from a fixed smooth pattern, which keeps more of the frame below the tone map's white."""
     import torch
 
     from raymarching_amd import Engine
@@ -82,35 +85,47 @@ def test_stress_frame_rows_at_7680x4320():
 
     w, h = 7680, 4320
     scene = stress_scene(250, boxes=True, smooth_union=0.08)
-    lm = stress_lightmap_pattern()
+    lit = [i for i, obj in enumerate(scene.objects) if not isinstance(obj, Box)]
     eng = Engine(scene, w, h)
     ora = make_oracle(scene)
-    for i, obj in enumerate(scene.objects):
-        if not isinstance(obj, Box):
-            eng.set_lightmap(i, lm)
-            ora.set_lightmap(i, lm)
     eng.set_march_cap(1024)
-    frame = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
     eng.input(0, 0, (0.0, 0.0, 0.0), 0)
-    digests = []
-    for _ in range(2):
-        eng.render_rows_device(frame.data_ptr(), 0, h)
-        eng.synchronize()
-        host = frame.cpu().numpy()
-        digests.append(hashlib.sha256(host.tobytes()).hexdigest())
-    assert digests[0] == digests[1], "the frame must be bit-stable from run to run"
-    st = eng.stats()
-    assert st["step_cap_hits"] == 0 and st["depth_cap_hits"] == 0 and st["lightmap_oob"] == 0, st
+    frame = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+
+    def rendered_twice():
+        digests = []
+        for _ in range(2):
+            eng.render_rows_device(frame.data_ptr(), 0, h)
+            eng.synchronize()
+            host = frame.cpu().numpy()
+            digests.append(hashlib.sha256(host.tobytes()).hexdigest())
+        assert digests[0] == digests[1], "the frame must be bit-stable from run to run"
+        st = eng.stats()
+        assert st["step_cap_hits"] == 0 and st["depth_cap_hits"] == 0 and st["lightmap_oob"] == 0, st
+        return host
+
+    def rows_against_oracle(host, rows, what):
+        worst, off = 0, 0
+        for y in rows:
+            ref = ora.render(w, h, rows=(y, y + 1), threads=THREADS)
+            mx, exact = frame_stats(host[y:y + 1], ref)
+            worst, off = max(worst, mx), off + round((1 - exact) * w)
+        print(f"7680x4320 stress rows {rows}, {what}: max|d| = {worst}, {off} of {len(rows) * w} pixels differ")
+        assert worst <= 1 and off <= 2
+
+    eng.compute_lightmaps(4)  # what the benchmark does before its frame loop
+    for i in lit:
+        values = eng.get_lightmap(i)
+        assert np.isfinite(values).all()
+        ora.set_lightmap(i, values)
+    rows_against_oracle(rendered_twice(), [611, 2160, 3333, 4319], "lightmaps of the precompute")
+    lm = stress_lightmap_pattern()
+    for i in lit:
+        eng.set_lightmap(i, lm)
+        ora.set_lightmap(i, lm)
+    rows_against_oracle(rendered_twice(), [5, 1500, 2701, 3900], "pattern lightmaps")
     eng.close()
-    rows = [5, 611, 1500, 2160, 2701, 3333, 3900, 4319]
-    worst, off = 0, 0
-    for y in rows:
-        ref = ora.render(w, h, rows=(y, y + 1), threads=THREADS)
-        mx, exact = frame_stats(host[y:y + 1], ref)
-        worst, off = max(worst, mx), off + round((1 - exact) * w)
     ora.close()
-    print(f"7680x4320 stress rows {rows}: max|d| = {worst}, {off} of {len(rows) * w} pixels differ")
-    assert worst <= 1 and off <= 4
 
 
 def test_lightmaps_at_map_size_16(scene):
