@@ -108,8 +108,13 @@ RM_DEV float mag_sqd(V3 a) { return (a.x * a.x + a.y * a.y) + a.z * a.z; }
 RM_DEV float sqrt_rn(float x);
 RM_DEV float mag(V3 a) { return sqrt_rn(mag_sqd(a)); }  // vector.rs:22
 // vector.rs:27-30: reciprocal then multiply
+RM_DEV bool sqrt_fast_range(float x);
+RM_DEV float sqrt_rn_in_range(float x);
+RM_DEV float recip_rn_in_range(float b);
 RM_DEV V3 normalized(V3 a) {
-    float inv = 1.0f / mag(a);
+    const float m = mag_sqd(a);
+    // (a root in [2^-48, 2^48) is within the range of the shared-work reciprocal)
+    const float inv = wave_all(sqrt_fast_range(m)) ? recip_rn_in_range(sqrt_rn_in_range(m)) : 1.0f / sqrtf(m);
     return a * inv;
 }
 RM_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }  // vector.rs:32
@@ -131,6 +136,14 @@ RM_DEV float rs_clamp(float x, float lo, float hi) {
 }
 RM_DEV float rs_max(float a, float b) { return fmaxf(a, b); }
 RM_DEV float rs_min(float a, float b) { return fminf(a, b); }
+// The same minimum as one bare v_min_f32.  Where an operand reaches fminf across a branch the
+// compiler first re-quiets it (v_max_f32 x, x: it cannot see that no signalling NaN exists here,
+// arithmetic never produces one); the instruction itself already drops a quiet NaN operand.
+RM_DEV float rs_min_bare(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 RM_DEV float powi5(float x) {
     float sq = x * x;
@@ -173,24 +186,60 @@ RM_DEV float smooth_min(float a, float b, float k) {
     return rs_min(a, b) - h * h * k * (1.0f / 4.0f);
 }
 
-// Correctly rounded square root.  v_sqrt_f32 is within one ulp; the two fused
-// residuals pick the correctly rounded neighbour, which is what the compiler's
-// own IEEE expansion does after rescaling its input.  Inputs that would need the
-// rescaling (below 2^-96), zeros, infinities, negatives and NaNs take that
-// full expansion instead.
+// Correctly rounded square root.  v_sqrt_f32 is within one ulp; its residual x - s*s (exact in one
+// fused operation) times half the reciprocal root, added to s in a second fused operation, rounds
+// to the correctly rounded root: checked against the double-precision root for every float in
+// [2^-96, inf) on the GPU (tools/sqrt_exhaustive.hip: no mismatch among 1,879,048,192 inputs).
+// Smaller inputs, zeros, infinities, negatives and NaNs take the compiler's full IEEE expansion.
+RM_DEV bool sqrt_fast_range(float x) {  // 2^-96 <= x < 2^96, as one unsigned compare of the bit pattern
+    return (unsigned)(__float_as_int(x) - 0x0F800000) < (unsigned)(0x6F800000 - 0x0F800000);
+}
+RM_DEV float sqrt_rn_in_range(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+    const float d = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(h, d, s);
+}
 RM_DEV float sqrt_rn(float x) {
     // One scalar branch for the whole wave: the special inputs practically never
     // occur, and a per-lane branch would cost more mask bookkeeping than it saves.
-    if (wave_all(x >= 0x1p-96f && x < __builtin_inff())) {
-        float s = __builtin_amdgcn_sqrtf(x);
-        float sd = __int_as_float(__float_as_int(s) - 1);
-        float su = __int_as_float(__float_as_int(s) + 1);
-        float rd = __builtin_fmaf(-sd, s, x);
-        float ru = __builtin_fmaf(-su, s, x);
-        float r = (rd <= 0.0f) ? sd : s;
-        return (ru > 0.0f) ? su : r;
-    }
+    if (wave_all(sqrt_fast_range(x))) return sqrt_rn_in_range(x);
     return sqrtf(x);
+}
+
+// Correctly rounded division for operands in a known range, with the work on the divisor shared
+// between dividends.  v_rcp_f32 refined by one Newton step is the correctly rounded reciprocal, and
+// a * y corrected once by its exact residual a - b*q is the correctly rounded quotient: both checked
+// on the GPU against the compiler's IEEE division for every pair of mantissas (tools/div_exhaustive.hip:
+// no mismatch among 2^46 pairs; tools/sqrt_exhaustive.hip for the reciprocal alone).  Powers of two
+// scale every intermediate exactly as long as none leaves the normal range, which the callers ensure:
+//   recip_rn_in_range(b):    2^-100 <= |b| <= 2^100
+//   div_rn_in_range(a, b, y): y = recip_rn_in_range(b), b > 0; a = +-0, or |a| >= 2^-100 with
+//                            2^-120 <= |a / b| <= 2^120 (the residual of a smaller dividend is not
+//                            representable).  A zero dividend keeps its sign, as in a / b with b > 0:
+//                            the correction step alone would turn -0 into +0.
+RM_DEV bool float_bits_within(float x, int lo_bits, int hi_bits) {  // lo <= x < hi for positive bounds, one unsigned compare
+    return (unsigned)(__float_as_int(x) - lo_bits) < (unsigned)(hi_bits - lo_bits);
+}
+RM_DEV float recip_rn_in_range(float b) {
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+RM_DEV float div_rn_in_range(float a, float b, float y) {
+    const float q0 = a * y;
+    const float r = __builtin_fmaf(-b, q0, a);
+    const float q = __builtin_fmaf(r, y, q0);
+    return __builtin_copysignf(q, a);
+}
+// true where x, y and z are each +-0 or at least 2^-90 in magnitude: twice the magnitude bits
+// minus 2 wraps a zero around to the top of the unsigned range
+RM_DEV bool zero_or_above_2m90(float x, float y, float z) {
+    const unsigned tx = ((unsigned)__float_as_int(x) << 1) + 0xfffffffeu;
+    const unsigned ty = ((unsigned)__float_as_int(y) << 1) + 0xfffffffeu;
+    const unsigned tz = ((unsigned)__float_as_int(z) << 1) + 0xfffffffeu;
+    const unsigned lowest = min(tx, min(ty, tz));
+    return lowest >= (0x12800000u << 1) - 2u;  // 0x12800000 = 2^-90
 }
 
 // ---------------------------------------------------------------------------
@@ -619,7 +668,13 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, LaneMask act, SphereB
             const float m = mag_sqd(p - v3(cx, cy, cz));
             const float rough = ign.mask(oi, __builtin_amdgcn_sqrtf(m) - r);
             nearest = rs_min(nearest, rough);
-            if (!(rough > decide)) fold(ign.mask(oi, sqrt_rn(m) - r));
+            if (!(rough > decide)) {
+                const float exact = ign.mask(oi, sqrt_rn(m) - r);
+                if (blend)
+                    d = smooth_min(d, exact, k);
+                else
+                    d = rs_min_bare(d, exact);
+            }
         });
         sb.T = __builtin_fmaf(travelled, sb.dn, nearest - sb.M);
     }
@@ -914,10 +969,12 @@ RM_DEV V3 texture_sample(const TextureRec &t, float u, float v) {
     float ax = floorf(fabsf(u * t.uscale)), ay = floorf(fabsf(v * t.vscale));
     float fw = (float)t.w, fh = (float)t.h;
     float fx, fy;
-    if (t.pow2) {
+    if (t.inv_w != 0.0f) {
         // x mod 2^k for a non-negative integer-valued x: every step below is exact
-        fx = ax - fw * floorf(ax / fw);
-        fy = ay - fh * floorf(ay / fh);
+        // (the quotient by a power of two is the product with its reciprocal, exactly: ax and ay are
+        // whole numbers, infinite or NaN)
+        fx = ax - fw * floorf(ax * t.inv_w);
+        fy = ay - fh * floorf(ay * t.inv_h);
     } else {
         fx = fmodf(ax, fw);
         fy = fmodf(ay, fh);
@@ -1031,10 +1088,9 @@ RM_DEV V3 sample_lightmap(const SceneView &sv, const ShadeRec &sr, const Geom &g
 }
 
 // colour.rs:74-98
-RM_DEV void phong_ds(V3 n, V3 l, float dist, float intensity, const ShadeRec &m, V3 view, float &diffuse,
-                     float &specular) {
+// (`li` = intensity / (dist * dist), colour.rs:83, formed by the caller)
+RM_DEV void phong_ds(V3 n, V3 l, float li, const ShadeRec &m, V3 view, float &diffuse, float &specular) {
     V3 r = reflect(l, n);
-    float li = intensity / (dist * dist);
     diffuse = m.diffuse * li * rs_max(dot(l, n), 0.0f);
     specular = 0.0f;
     if (diffuse > 0.0f) {
@@ -1044,6 +1100,29 @@ RM_DEV void phong_ds(V3 n, V3 l, float dist, float intensity, const ShadeRec &m,
         bool zero = (m.specular == 0.0f) && (m.shininess >= 0.0f) && (li > 0.0f) && (li < __builtin_inff()) &&
                     (base < __builtin_inff());
         if (!zero) specular = m.specular * li * powf(base, m.shininess);
+    }
+}
+
+// engine.rs:171-173 and colour.rs:83: dist = |to_light|, to_light / dist (three divisions by one
+// divisor), li = intensity / (dist * dist).  A wave whose lanes all hold values in the usual range
+// (distances between 2^-20 and 2^20, a light intensity between 2^-40 and 2^40, no vector component
+// below 2^-90 other than zero) shares the work on each divisor; any other wave takes the compiler's
+// IEEE divisions.  Both deliver the same correctly rounded values.
+RM_DEV void light_terms(V3 &to_light, float intensity, float &dist, float &li) {
+    const float m = mag_sqd(to_light);
+    const bool usual = float_bits_within(m, 0x2B800000, 0x53800000) &            // 2^-40 <= m < 2^40
+                       float_bits_within(intensity, 0x2B800000, 0x53800000) &    // (the same in every lane)
+                       zero_or_above_2m90(to_light.x, to_light.y, to_light.z);
+    if (wave_all(usual)) {
+        dist = sqrt_rn_in_range(m);
+        const float y = recip_rn_in_range(dist);
+        to_light = v3(div_rn_in_range(to_light.x, dist, y), div_rn_in_range(to_light.y, dist, y), div_rn_in_range(to_light.z, dist, y));
+        const float d2 = dist * dist;
+        li = div_rn_in_range(intensity, d2, recip_rn_in_range(d2));
+    } else {
+        dist = sqrt_rn(m);
+        to_light = to_light / dist;
+        li = intensity / (dist * dist);
     }
 }
 
@@ -1073,11 +1152,11 @@ RM_DEV ShadeResult shade_local(const SC &sc, const SceneView &sv, int idx, V3 po
 
     V3 light = v3(sv.light[0], sv.light[1], sv.light[2]);
     V3 to_light = light - pos;
-    float dist = mag(to_light);
-    to_light = to_light / dist;
+    float dist, li;
+    light_terms(to_light, sv.intensity, dist, li);
 
     float diffuse = 0.5f, specular = 0.0f;
-    if (!(RM_ABL & 128)) phong_ds(n, to_light, dist, sv.intensity, sr, dir, diffuse, specular);
+    if (!(RM_ABL & 128)) phong_ds(n, to_light, li, sr, dir, diffuse, specular);
     diag_lap(DG_SHADE);
     // engine.rs:194 multiplies the shade by diffuse + specular: where that is +-0 (the surface faces
     // away from the light) the product is that zero for any shade - a finite value in [0, 1] - and the

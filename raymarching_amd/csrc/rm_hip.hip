@@ -74,7 +74,11 @@ __device__ __forceinline__ void tile_pixel(const RenderArgs &a, int &x, int &y_i
 // (72 registers, 7 waves) is left alone.
 template <class G>
 struct MinWaves {
+#ifdef RM_EXP_MINWAVES
+    static constexpr int value = RM_EXP_MINWAVES;
+#else
     static constexpr int value = 1;
+#endif
 };
 template <>
 struct MinWaves<GroupedLarge> {
@@ -85,6 +89,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, MinWaves<G>::value) void render_kern
     int x, y_inv, out_row;
 #ifdef RM_DIAG_TIME
     const unsigned long long diag_t0 = wall_clock64();
+    const unsigned long long diag_c0 = __builtin_readcyclecounter();
 #endif
     tile_pixel(a, x, y_inv, out_row);
 #ifdef RM_DIAG
@@ -127,6 +132,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, MinWaves<G>::value) void render_kern
         if (threadIdx.x == 0) px = (unsigned)diag_t0;
         if (threadIdx.x == 1) px = (unsigned)t1;
         if (threadIdx.x == 2) px = hw;
+#ifndef RM_DIAG
+        if (threadIdx.x == 3) px = (unsigned)(__builtin_readcyclecounter() - diag_c0);  // shader-clock cycles of the wave
+#endif
 #ifdef RM_DIAG
         // with the iteration counters also built in: loop iterations of the wave, of its busiest
         // lane, summed over lanes, and the number of marches
@@ -1290,7 +1298,7 @@ static int engine_upload(rm_engine *e) {
         HIP_TRY(dev_alloc(&e->d_texels[t], ht.texels.size()));
         HIP_TRY(hipMemcpy(e->d_texels[t], ht.texels.data(), sizeof(float) * ht.texels.size(), hipMemcpyHostToDevice));
         const bool pow2 = (ht.w & (ht.w - 1)) == 0 && (ht.h & (ht.h - 1)) == 0;
-        tex[t] = TextureRec{e->d_texels[t], ht.w, ht.h, ht.uscale, ht.vscale, pow2 ? 1 : 0, 0};
+        tex[t] = TextureRec{e->d_texels[t], ht.w, ht.h, ht.uscale, ht.vscale, pow2 ? 1.0f / (float)ht.w : 0.0f, pow2 ? 1.0f / (float)ht.h : 0.0f};
     }
     HIP_TRY(dev_alloc(&e->d_tex, tex.size()));
     if (!tex.empty()) HIP_TRY(hipMemcpy(e->d_tex, tex.data(), sizeof(TextureRec) * tex.size(), hipMemcpyHostToDevice));

@@ -15,7 +15,10 @@ constexpr float STEP_SIZE = 0.0001f;
 // engine.rs:192
 constexpr float SHADOW_K = 16.0f;
 
-constexpr int MAX_DEPTH = 16;  // explicit reflection stack (the reference recurses without bound)
+#ifndef RM_MAX_DEPTH
+#define RM_MAX_DEPTH 16
+#endif
+constexpr int MAX_DEPTH = RM_MAX_DEPTH;  // explicit reflection stack (the reference recurses without bound)
 
 // Geometry of one object, 32 bytes.
 //   sphere      : cx, cy, cz, radius
@@ -42,8 +45,7 @@ struct TextureRec {
     const float *texels;  // [h][w][4] floats, rgb already squared as rgb! does (colour.rs:7-15)
     int w, h;
     float uscale, vscale;
-    int pow2;  // w and h are powers of two: the wrap of texture.rs:32-33 needs no fmod
-    int pad;
+    float inv_w, inv_h;  // 1/w and 1/h where w and h are both powers of two (the wrap of texture.rs:32-33 then needs no fmod), else 0
 };
 
 // The march loops see the scene grouped by primitive type, so that they run

@@ -25,7 +25,14 @@ if only is not None:
     img = buf.cpu().numpy()
     H = 8
 else:
-    img = e.render(None, 0, 0, (0, 0, 0), 0)
+    # (one launch for the whole frame, as the benchmark renders it: rm_engine_render would send a
+    # large frame in row bands)
+    buf = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    e.input(0, 0, (0, 0, 0), 0)
+    for _ in range(2):
+        e.render_rows_device(buf.data_ptr(), 0, H)
+    e.synchronize()
+    img = buf.cpu().numpy()
 px = img.view(np.uint32).reshape(H, W)
 t0 = px[0::8, 0::8].astype(np.int64)
 t1 = px[0::8, 1::8].astype(np.int64)
@@ -37,6 +44,21 @@ print(f"waves {dur.size}: mean {dur.mean():.2f} us, median {np.median(dur):.2f},
 print(f"grid span {end.max():.1f} us; sum of wave lifetimes {dur.sum() / 1e3:.1f} ms -> mean resident waves {dur.sum() / end.max():.0f}")
 for q in (50, 75, 90, 95, 99, 100):
     print(f"  {q:3d} % of waves had ended by {np.percentile(end, q):.1f} us")
+# resident waves over the span, in 20 bins, and how evenly the compute units were used
+edges = np.linspace(0.0, end.max(), 21)
+res = [int(((start.ravel() < b) & (end.ravel() > a)).sum() * 1.0) for a, b in zip(edges[:-1], edges[1:])]
+print("  waves alive in each 1/20 of the span (a wave counts in every bin it touches): " + " ".join(str(r) for r in res))
+cu_key = (hw.ravel() >> 8) & 0xFFFF  # HW_ID above the wave and SIMD fields: CU, SH, SE (the XCD is not in HW_ID)
+busy = {}
+for k, d in zip(cu_key.tolist(), dur.ravel().tolist()):
+    busy[k] = busy.get(k, 0.0) + d
+b = np.array(sorted(busy.values()))
+print(f"  {len(b)} distinct HW_ID compute-unit keys; summed wave lifetime per key: min {b.min():.0f} us, median {np.median(b):.0f}, max {b.max():.0f}")
+if not os.environ.get("RM_DIAG_BOTH"):
+    cyc = px[0::8, 3::8].astype(np.int64)
+    long_enough = dur > 5.0
+    mhz = cyc[long_enough] / dur[long_enough]
+    print(f"  shader clock over waves longer than 5 us: median {np.median(mhz):.0f} MHz, p5 {np.percentile(mhz, 5):.0f}, p95 {np.percentile(mhz, 95):.0f}")
 order = np.argsort(end.ravel())[-8:]
 for i in order:
     ty, tx = divmod(int(i), W // 8)
