@@ -1110,9 +1110,10 @@ RM_DEV void phong_ds(V3 n, V3 l, float li, const ShadeRec &m, V3 view, float &di
 // IEEE divisions.  Both deliver the same correctly rounded values.
 RM_DEV void light_terms(V3 &to_light, float intensity, float &dist, float &li) {
     const float m = mag_sqd(to_light);
-    const bool usual = float_bits_within(m, 0x2B800000, 0x53800000) &            // 2^-40 <= m < 2^40
-                       float_bits_within(intensity, 0x2B800000, 0x53800000) &    // (the same in every lane)
-                       zero_or_above_2m90(to_light.x, to_light.y, to_light.z);
+    // (bitwise on purpose: three cheap tests, no short-circuit branches)
+    const bool usual = (int)float_bits_within(m, 0x2B800000, 0x53800000) &            // 2^-40 <= m < 2^40
+                       (int)float_bits_within(intensity, 0x2B800000, 0x53800000) &    // (the same in every lane)
+                       (int)zero_or_above_2m90(to_light.x, to_light.y, to_light.z);
     if (wave_all(usual)) {
         dist = sqrt_rn_in_range(m);
         const float y = recip_rn_in_range(dist);
