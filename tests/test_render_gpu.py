@@ -184,6 +184,56 @@ def test_probe_shade_matches_oracle(scene, gpu_engine, oracle_lightmaps):
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("intensity", [3.5, 2.0 ** 41, 2.0 ** -41])
+def test_probe_shade_outside_the_usual_ranges(scene, oracle_lightmaps, intensity):
+    """The light terms of shade_object (distance, direction, intensity / distance^2) where the
+    kernel's shared-work roots and quotients do not apply and the IEEE expansions run instead: a
+    light intensity outside [2^-40, 2^40), points whose offset from the light has a component that is
+    tiny but not zero, exactly zero, or huge, and points at the light itself."""
+    import copy
+
+    from raymarching_amd import Engine
+
+    lm, _ = oracle_lightmaps
+    sc = copy.deepcopy(scene)
+    sc.light.intensity = float(np.float32(intensity))
+    lx, ly, lz = (float(np.float32(v)) for v in sc.light.position)
+    pts = np.array([
+        [lx + 1e-33, -1.0, 0.5],      # a component below 2^-90 that is not zero
+        [lx, ly + 1.0, lz],           # two components exactly zero
+        [lx - 1e-33, ly, lz + 2e-36],  # every component tiny: the squared distance underflows
+        [3e11, 0.5, -2e11],           # squared distance above 2^40
+        [1e20, 1e20, 1e20],           # squared distance overflows
+        [lx, ly, lz],                 # at the light: distance zero
+        [0.3, -1.0, 0.2], [-1.0, 0.4, 0.1], [0.0, 0.5, 2.0],  # ordinary points
+    ], dtype=np.float32)
+    dirs = np.tile(np.array([[0.0, 0.0, 1.0]], dtype=np.float32), (len(pts), 1))
+    eng = Engine(sc, 64, 64)
+    ora = make_oracle(sc, lm[-1])
+    for i, values in enumerate(lm[-1]):
+        if values is not None:
+            eng.set_lightmap(i, values)
+    # a sphere and three untextured planes (at the absurd coordinates the floor's texture lookup is
+    # not a number in different channels here and in the oracle, whatever the light terms do)
+    chosen = [i for i, o in enumerate(sc.objects) if type(o).__name__ == "Sphere"][:1]
+    chosen += [i for i, o in enumerate(sc.objects) if type(o).__name__ != "Sphere" and getattr(o, "texture", None) is None][:3]
+    assert len(chosen) == 4
+    worst = 0.0
+    for obj in chosen:
+        objs = np.full(len(pts), obj, dtype=np.int32)
+        got = eng.probe_shade(objs, pts, dirs)
+        ref = np.stack([ora.shade(obj, p, d) for p, d in zip(pts, dirs)])
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), (obj, got, ref)
+        assert np.array_equal(np.isinf(got), np.isinf(ref)), (obj, got, ref)
+        ok = np.isfinite(ref)
+        # linear colours: identical up to the last-bit freedom of powf/atan2f
+        np.testing.assert_allclose(got[ok], ref[ok], rtol=2e-5, atol=1e-30)
+        worst = max(worst, float(np.max(np.abs(got[ok] - ref[ok]) / np.maximum(np.abs(ref[ok]), 1e-30), initial=0.0)))
+    print(f"intensity {intensity:g}: largest relative difference {worst:.2e}")
+    eng.close()
+    ora.close()
+
+
 def test_headless_host_harness(tmp_path, scene, oracle_lightmaps):
     """The C++ host mirror of main.rs (host/main.cpp) renders the default frame through the C ABI."""
     import os
