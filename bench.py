@@ -497,7 +497,8 @@ def main():
                 "frac_of_no_fma_peak": achieved / PEAK_FP32_NO_FMA_TFLOPS,
                 "traffic": int(measured_traffic(W, H) * band_share) if measured_traffic(W, H) else None,
                 "traffic_source": "rocprofv3 PMC passes committed under profiles/ (not collected live)",
-                "kernel": "render_kernel",
+                # (a launch of 65536 tiles or more of a small scene runs the build of the kernel for 8 waves per SIMD)
+                "kernel": "render_dense_kernel" if ((W + 7) // 8) * ((r1 - r0 + 7) // 8) >= 65536 and not args.ssaa and not args.refraction else "render_kernel",
                 "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": int(flops * band_share),
                 "note": "FP32 vector ALU bound (no MFMA, HBM traffic is 4 B per ray); strict IEEE parity forbids FMA contraction",

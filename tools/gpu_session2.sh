@@ -43,7 +43,7 @@ pmc fxaa_write "WRITE_SIZE" python3 tools/fxaa_bench.py
 pmc rad64_fetch "FETCH_SIZE" python3 bench.py --workload radiosity --map-size 64 --steps 2 --warmup 1 --no-cpu-baseline
 pmc rad64_write "WRITE_SIZE" python3 bench.py --workload radiosity --map-size 64 --steps 2 --warmup 1 --no-cpu-baseline
 {
-  for p in sq fetch write; do python3 tools/pmc_brief.py render_kernel $out/pmc_$p/*.db; done
+  for p in sq fetch write; do python3 tools/pmc_brief.py render_ $out/pmc_$p/*.db; done
   for p in stress_sq stress_fetch stress_write; do python3 tools/pmc_brief.py render_kernel $out/pmc_$p/*.db; done
   for p in fxaa_fetch fxaa_write; do python3 tools/pmc_brief.py fxaa_kernel $out/pmc_$p/*.db; done
   for p in rad64_fetch rad64_write; do python3 tools/pmc_brief.py rad_ $out/pmc_$p/*.db; done
@@ -65,9 +65,9 @@ json.dump({"kernel": "render_kernel<GroupedLarge>", "workload": "stress scene 76
            "fetch_size_kib": fe["FETCH_SIZE"], "write_size_kib": wr["WRITE_SIZE"], "hbm_bytes_per_launch": int((2 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024),
            "how": "separate rocprofv3 --pmc passes (SQ counters; FETCH_SIZE; WRITE_SIZE) over tools/stress_frame.py; FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes)"},
           open(f"{out}/stress_pmc.json", "w"), indent=1)
-fe = counters(glob.glob(f"{out}/pmc_fetch/*.db")[0], "render_kernel")
-wr = counters(glob.glob(f"{out}/pmc_write/*.db")[0], "render_kernel")
-json.dump({"kernel": "render_kernel", "workload": "default scene 3840x2160", "fetch_size_kib": fe["FETCH_SIZE"], "write_size_kib": wr["WRITE_SIZE"],
+fe = counters(glob.glob(f"{out}/pmc_fetch/*.db")[0], "render_dense_kernel")
+wr = counters(glob.glob(f"{out}/pmc_write/*.db")[0], "render_dense_kernel")
+json.dump({"kernel": "render_dense_kernel", "workload": "default scene 3840x2160", "fetch_size_kib": fe["FETCH_SIZE"], "write_size_kib": wr["WRITE_SIZE"],
            "hbm_bytes_per_launch": int((2 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024),
            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE GRBM_GUI_ACTIVE in separate passes over tools/profile_frame.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 tallies 128-byte read requests at 64 bytes)"},
           open(f"{out}/traffic.json", "w"), indent=1)

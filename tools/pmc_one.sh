@@ -10,5 +10,5 @@ for lib in "$@"; do
     export RM_LIB=$lib
     timeout -s KILL 90 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_TRANS SQ_WAVES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $out -o pmc -- python3 tools/profile_frame.py > $out.log 2>&1 || exit 1
     echo "== $tag"
-    python3 tools/pmc_brief.py render_kernel $out/*.db
+    python3 tools/pmc_brief.py render_ $out/*.db
 done
