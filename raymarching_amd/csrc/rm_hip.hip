@@ -1398,10 +1398,21 @@ static void engine_free(rm_engine *e) {
 }
 
 // Launches KERNEL<G>(args..., grouped scene) for the engine's scene tier.
+// -DRM_EXP_LDS: a diagnostic build whose kernels of the small exact-fill tier are launched with
+// RM_EXP_LDS (environment) bytes of unused LDS per workgroup, which caps the waves a compute unit
+// holds (tools/occupancy_probe.py).
+#ifdef RM_EXP_LDS
+static size_t exp_lds_bytes() {
+    static const size_t n = getenv("RM_EXP_LDS") ? (size_t)atoi(getenv("RM_EXP_LDS")) : 0;
+    return n;
+}
+#else
+static constexpr size_t exp_lds_bytes() { return 0; }
+#endif
 #define RM_LAUNCH(KERNEL, e, grid, block, ...)                                                                \
     do {                                                                                                      \
         if ((e)->tier == -1)                                                                                  \
-            hipLaunchKernelGGL((KERNEL<GroupedTierX>), grid, block, 0, (e)->stream, __VA_ARGS__, (e)->tier_x); \
+            hipLaunchKernelGGL((KERNEL<GroupedTierX>), grid, block, exp_lds_bytes(), (e)->stream, __VA_ARGS__, (e)->tier_x); \
         else if ((e)->tier == 0)                                                                              \
             hipLaunchKernelGGL((KERNEL<GroupedTierA>), grid, block, 0, (e)->stream, __VA_ARGS__, (e)->tier_a); \
         else if ((e)->tier == 1)                                                                              \

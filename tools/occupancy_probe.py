@@ -1,5 +1,6 @@
 """Frame time at 4K with the render kernel's residency capped by a dummy LDS allocation per workgroup
-(RM_EXP_LDS bytes, read once per process by a build that has the knob: one child process per setting)."""
+(RM_EXP_LDS bytes, read once per process by a build made with `make EXTRA=-DRM_EXP_LDS OUT=...`: one
+child process per setting).  usage: occupancy_probe.py lib.so bytes [bytes ...]"""
 import os
 import subprocess
 import sys
