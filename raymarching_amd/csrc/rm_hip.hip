@@ -127,8 +127,10 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, const G &g) {
     // and the compute unit it ran on, instead of colours
     {
         const unsigned long long t1 = wall_clock64();
-        unsigned hw;
+        unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        hw = (hw & 0x0FFFFFFFu) | (xcc << 28);  // the die in place of the queue and state fields
         if (threadIdx.x == 0) px = (unsigned)diag_t0;
         if (threadIdx.x == 1) px = (unsigned)t1;
         if (threadIdx.x == 2) px = hw;

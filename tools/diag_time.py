@@ -48,7 +48,16 @@ for q in (50, 75, 90, 95, 99, 100):
 edges = np.linspace(0.0, end.max(), 21)
 res = [int(((start.ravel() < b) & (end.ravel() > a)).sum() * 1.0) for a, b in zip(edges[:-1], edges[1:])]
 print("  waves alive in each 1/20 of the span (a wave counts in every bin it touches): " + " ".join(str(r) for r in res))
-cu_key = (hw.ravel() >> 8) & 0xFFFF  # HW_ID above the wave and SIMD fields: CU, SH, SE (the XCD is not in HW_ID)
+# how long a wave slot (die, shader engine, array, compute unit, SIMD, wave id) stands empty between
+# the end of one wave and the first instruction of the next
+slot = (hw.ravel().astype(np.int64) & 0xF000FF3F)  # die | SE, SH, CU | SIMD | wave id
+order_s = np.lexsort((start.ravel(), slot))
+s_sorted, st_sorted, en_sorted = slot[order_s], start.ravel()[order_s], end.ravel()[order_s]
+same = s_sorted[1:] == s_sorted[:-1]
+gaps = (st_sorted[1:] - en_sorted[:-1])[same]
+print(f"  {len(np.unique(slot))} wave slots seen; gap between consecutive waves of a slot: median {np.median(gaps):.2f} us, mean {gaps.mean():.2f}, "
+      f"p10 {np.percentile(gaps, 10):.2f}, p90 {np.percentile(gaps, 90):.2f}, p99 {np.percentile(gaps, 99):.2f}; negative {int((gaps < 0).sum())}")
+cu_key = (hw.ravel() >> 8) & 0xFFFF  # HW_ID above the wave and SIMD fields: CU, SH, SE
 busy = {}
 for k, d in zip(cu_key.tolist(), dur.ravel().tolist()):
     busy[k] = busy.get(k, 0.0) + d
@@ -83,3 +92,4 @@ if os.environ.get("RM_DIAG_BOTH"):
     print(f"  slowest 1 % of waves: iterations {it[heavy].mean():.0f}, busiest lane {busiest[heavy].mean():.0f}, mean lane {lanes[heavy].mean() / 64:.0f}")
 np.save("gpurun_out/diag_time_dur.npy", dur.astype(np.float32))
 np.save("gpurun_out/diag_time_start.npy", start.astype(np.float32))
+np.save("gpurun_out/diag_time_hw.npy", hw.astype(np.uint32))
