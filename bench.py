@@ -383,11 +383,37 @@ def main():
 
         if backend == "nccl":
             # the 128-byte id is the only thing the ranks exchange outside the library
-            ids = [unique_id() if rank == 0 else None]
+            failure = None
+            try:
+                ids = [unique_id() if rank == 0 else None]
+            except Exception as exc:  # (no RCCL to be found: every rank must still reach the broadcast)
+                ids, failure = [None], f"{type(exc).__name__}: {exc}"
             if world > 1:
                 dist.broadcast_object_list(ids, src=0)
-            group = Group(eng, rank, world, ids[0], frames_in_flight=in_flight)
-        else:
+            if ids[0] is None:
+                failure = failure or "rank 0 could not make a communicator id"
+            else:
+                try:
+                    if os.environ.get("RM_BENCH_FAIL_RCCL") == "1":  # rehearsal of the fallback below
+                        raise RuntimeError("failure requested by RM_BENCH_FAIL_RCCL")
+                    group = Group(eng, rank, world, ids[0], frames_in_flight=in_flight)
+                except Exception as exc:
+                    failure = f"{type(exc).__name__}: {exc}"
+            # The transport is the ranks' common choice: if the communicator could not be built on any
+            # rank, all of them hand the library the host all-gather below instead (same frames, a
+            # slower exchange), and the line says so.  The rendering is the library's either way.
+            failures = [None] * world
+            if world > 1:
+                dist.all_gather_object(failures, failure)
+            else:
+                failures = [failure]
+            if any(failures):
+                if group is not None:
+                    group.close()
+                    group = None
+                backend = "gloo (RCCL communicator failed: " + next(f for f in failures if f)[:200] + ")"
+                print(f"[bench] rank {rank}: {backend}", file=sys.stderr)
+        if group is None:
             # rehearsal on one GPU: RCCL refuses two ranks on one device, so the all-gather goes
             # through host memory and gloo; everything else is the path above
             def host_all_gather(d_send, d_recv, nbytes, hip_stream):
@@ -395,8 +421,11 @@ def main():
 
                 torch.cuda.synchronize()
                 mine = _alias_u8(d_send, nbytes, local_rank).cpu()
-                everyone = torch.empty(nbytes * world, dtype=torch.uint8)
-                dist.all_gather_into_tensor(everyone, mine)
+                if world > 1:
+                    everyone = torch.empty(nbytes * world, dtype=torch.uint8)
+                    dist.all_gather_into_tensor(everyone, mine)
+                else:
+                    everyone = mine
                 _alias_u8(d_recv, nbytes * world, local_rank).copy_(everyone)
                 torch.cuda.synchronize()
                 return 0
@@ -527,7 +556,7 @@ def main():
                 "height": H,
                 "bands": world,
                 "sharding": "interleaved 8-row strips" if gathering else "none",
-                "exchange": ("one all-gather per frame inside the library (rm_group_frame), " + ("RCCL" if backend == "nccl" else "gloo through host memory (rehearsal)")) if gathering else None,
+                "exchange": ("one all-gather per frame inside the library (rm_group_frame), " + ("RCCL" if backend == "nccl" else ("gloo through host memory (rehearsal)" if backend == "gloo" else backend))) if gathering else None,
                 "fxaa_after_gather": bool(args.fxaa and gathering),
                 "fxaa": bool(args.fxaa),
                 "ssaa": 4 if args.ssaa else 1,
