@@ -445,6 +445,10 @@ def main():
     kernel_events = []
     # one GPU: frame s is rendered (and filtered) on streams[s % in_flight]
     streams = [stream] + [torch.cuda.Stream() for _ in range(in_flight - 1)]
+    if in_flight > 1:
+        # launches overlap: the machine is busy while a frame's slow tiles finish, and rendering them
+        # as quarter waves (rm_engine_set_tile_splitting) would only cost throughput
+        eng.set_tile_splitting(False)
 
     def render_whole(b, timed):
         st = torch.cuda.current_stream()

@@ -175,6 +175,10 @@ impl Engine {
     pub fn set_refraction(&mut self, on: bool) -> Result<(), Error> {
         check(unsafe { sys::rm_engine_set_refraction(self.handle, on as i32) })
     }
+    /// Slow tiles first and in quarters (small launches; on by default, the pixels do not depend on it).
+    pub fn set_tile_splitting(&mut self, on: bool) -> Result<(), Error> {
+        check(unsafe { sys::rm_engine_set_tile_splitting(self.handle, on as i32) })
+    }
 
     pub fn camera_position(&self) -> Result<Vec3, Error> {
         let mut p = [0.0f32; 3];

@@ -196,6 +196,8 @@ class Engine {
 
     // engine.rs:196-228 (commented out there): reflective objects also refract
     void set_refraction(bool on) { for (rm_engine *e : engines_) check(rm_engine_set_refraction(e, on ? 1 : 0), "set_refraction"); }
+    // slow tiles first and in quarters (small launches; on by default, the pixels do not depend on it)
+    void set_tile_splitting(bool on) { for (rm_engine *e : engines_) check(rm_engine_set_tile_splitting(e, on ? 1 : 0), "set_tile_splitting"); }
 
     Vec3 camera_position() const {
         Vec3 p;

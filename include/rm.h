@@ -281,6 +281,18 @@ int rm_engine_set_refraction(rm_engine *engine, int on);
  * ends by itself after at most 50/0.001 steps).  Cut marches are counted. */
 int rm_engine_set_march_cap(rm_engine *engine, int max_steps);
 
+/* Slow tiles in quarters (no counterpart in the reference; the pixels do not depend on it).  A
+ * launch of fewer than 65536 tiles lasts as long as its slowest wave, so the frame kernel renders
+ * the tiles that took longest the last time they were rendered first and as four waves of 4x4
+ * pixels each (a quarter's pixels drift apart less between reflection levels: 0.6 of the time).
+ * On by default (RM_SPLIT_US in the environment sets the threshold for a quarter in microseconds,
+ * 0 switches it off).  A caller that keeps several launches of one engine in flight, where the
+ * machine is busy anyway and the quarters' idle lanes cost throughput, switches it off
+ * (rm_group_create does for more than one frame in flight).  rm_engine_split_tiles waits for the
+ * engine's work and reports how many tiles the most recent planned launch rendered in quarters. */
+int rm_engine_set_tile_splitting(rm_engine *engine, int on);
+int rm_engine_split_tiles(rm_engine *engine, uint32_t *count);
+
 /* Event counters accumulated since creation or the last reset (RM_STAT_*). */
 int rm_engine_get_stats(rm_engine *engine, uint64_t stats[RM_STAT_COUNT]);
 int rm_engine_reset_stats(rm_engine *engine);

@@ -74,6 +74,8 @@ SIGNATURES = {
     "rm_engine_set_tetrahedral_normals": (c_int, [c_void_p, c_int]),
     "rm_engine_set_refraction": (c_int, [c_void_p, c_int]),
     "rm_engine_set_march_cap": (c_int, [c_void_p, c_int]),
+    "rm_engine_set_tile_splitting": (c_int, [c_void_p, c_int]),
+    "rm_engine_split_tiles": (c_int, [c_void_p, POINTER(c_uint32)]),
     "rm_engine_get_stats": (c_int, [c_void_p, POINTER(c_uint64)]),
     "rm_engine_reset_stats": (c_int, [c_void_p]),
     "rm_engine_synchronize": (c_int, [c_void_p]),

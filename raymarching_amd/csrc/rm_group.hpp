@@ -174,6 +174,9 @@ static rm_group *group_build(rm_engine *e, int rank, int world, int frames_in_fl
     g->rank = rank;
     g->world = world;
     g->in_flight = frames_in_flight;
+    // with several frames in flight the machine is busy while a frame's slow tiles finish: the
+    // quarter waves of rm_engine_set_tile_splitting would only cost throughput
+    if (frames_in_flight > 1) e->split_on = false;
     const int strips = (e->H + RM_STRIP_ROWS - 1) / RM_STRIP_ROWS;
     g->strips_per_rank = (strips + world - 1) / world;
     g->band_pixels = (size_t)g->strips_per_rank * RM_STRIP_ROWS * e->W;

@@ -50,7 +50,58 @@ struct RenderArgs {
     // SMALL_DISTANCE to something, farther than MAX_MARCH_DISTANCE from everything, or not a number).
     float camera_dist, camera_sph;
     const float *screen_u, *screen_v;  // [W], [H]: engine.rs:79-82 per column and per row
+    // Slow tiles in quarters (see SplitPlan below); all null/0 for a launch without a plan.
+    const unsigned *plan_count;        // tiles on plan_list
+    const unsigned *plan_list;         // launch-local numbers of the tiles rendered by four waves
+    const unsigned char *plan_flag;    // [tiles of the launch]: 1 = on the list
+    unsigned *tile_cost;               // [tiles of the frame][4]: how long each quarter last took, 10 ns ticks
+    unsigned plan_cap;                 // the first 4 * plan_cap workgroups are the quarter waves
 };
+
+// Slow tiles in quarters.  A launch that does not fill the machine many times over lasts as long as
+// its slowest wave - in the default scene a tile in which two mirror spheres reflect each other:
+// 7-8 marches one after the other, and twice the loop iterations of its busiest pixel, because the
+// 64 pixels' chains drift apart.  Sixteen pixels drift apart less: the same tile as four waves of 16
+// active lanes has its slowest wave done in 0.6 of the time (measured on a full machine).  Which
+// tiles are slow is taken from the last time they were rendered: every wave leaves its lifetime in
+// `tile_cost` (a whole-tile wave 5/8 of it in all four slots, the scale of a quarter), and before a
+// launch `split_plan_kernel` lists the tiles whose slowest quarter reached the threshold.  The frame
+// kernel's first 4 * cap workgroups take the listed tiles' quarters (or leave at once), so the slow
+// tiles also start first; the workgroup of a listed tile in the usual order leaves at once.  The plan
+// belongs to its launch (list and flags are written before it in stream order and read by nothing
+// else), so every pixel is rendered exactly once whatever the history says; a wrong guess costs time
+// only.  The pixels do not depend on which wave renders them.
+constexpr unsigned kSplitThresholdTicks = 4500;  // 45 us for a quarter, 72 us for the whole tile (30-60 us measured alike)
+__device__ __forceinline__ unsigned frame_tile_of(const RenderArgs &a, int bx, int by) {
+    return (unsigned)((a.row_begin + by * a.tile_row_stride * TILE) / TILE) * (unsigned)a.blocks_x + (unsigned)bx;
+}
+__global__ __launch_bounds__(256) void split_plan_kernel(const RenderArgs a, unsigned *count, unsigned *list, unsigned char *flag,
+                                                         unsigned threshold) {
+    const unsigned t = blockIdx.x * 256 + threadIdx.x;
+    const unsigned n = (unsigned)(a.blocks_x * a.blocks_y);
+    bool slow = false;
+    if (t < n) {
+        const int by = a.blocks_y - 1 - (int)(t / (unsigned)a.blocks_x), bx = (int)(t % (unsigned)a.blocks_x);
+        const uint4 c = reinterpret_cast<const uint4 *>(a.tile_cost)[frame_tile_of(a, bx, by)];
+        slow = max(max(c.x, c.y), max(c.z, c.w)) >= threshold;
+    }
+    // one atomic per wave that has a slow tile
+    const unsigned long long slow_lanes = __builtin_amdgcn_ballot_w64(slow);
+    if (slow) {
+        const unsigned lane = threadIdx.x & 63;
+        const unsigned before = (unsigned)__builtin_popcountll(slow_lanes & ((1ULL << lane) - 1ULL));
+        unsigned base = 0;
+        if (before == 0) base = atomicAdd(count, (unsigned)__builtin_popcountll(slow_lanes));
+        base = __builtin_amdgcn_readfirstlane(base);  // (the first slow lane is the first active one here)
+        const unsigned at = base + before;
+        if (at < a.plan_cap)
+            list[at] = t;
+        else
+            slow = false;  // the list is full: the tile is rendered whole
+    }
+    if (t < n) flag[t] = slow ? 1 : 0;
+}
+
 
 // Workgroup -> tile.  Tiles are handed out bottom row first: in scenes with a
 // floor and things standing on it the lower rows cost most, and starting them
@@ -90,6 +141,42 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, const G &g) {
 #ifdef RM_DIAG_TIME
     const unsigned long long diag_t0 = wall_clock64();
     const unsigned long long diag_c0 = __builtin_readcyclecounter();
+#endif
+#if !defined(RM_DIAG) && !defined(RM_DIAG_TIME)
+    unsigned cost_at = 0, cost_t0 = 0;
+    bool quarter = false;
+    if (a.tile_cost) {  // (the same in every wave of the launch)
+        cost_t0 = (unsigned)wall_clock64();
+        unsigned tile = blockIdx.x;
+        if (a.plan_count) {
+            const unsigned first_whole = 4u * a.plan_cap;
+            if (blockIdx.x < first_whole) {
+                const unsigned listed = min(*a.plan_count, a.plan_cap);
+                if (blockIdx.x >= 4u * listed) return;
+                tile = a.plan_list[blockIdx.x >> 2];
+                quarter = true;
+            } else {
+                tile = blockIdx.x - first_whole;
+                if (a.plan_flag[tile]) return;
+            }
+        }
+        const int lane = threadIdx.x & 63;
+        const int by = a.blocks_y - 1 - (int)(tile / (unsigned)a.blocks_x), bx = (int)(tile % (unsigned)a.blocks_x);
+        int px, py;
+        if (quarter) {
+            const int q = blockIdx.x & 3;
+            px = (q & 1) * 4 + (lane & 3);
+            py = (q >> 1) * 4 + ((lane >> 2) & 3);
+            cost_at = frame_tile_of(a, bx, by) * 4 + q;
+        } else {
+            px = lane & 7;
+            py = lane >> 3;
+            cost_at = frame_tile_of(a, bx, by) * 4;
+        }
+        x = (quarter && lane >= 16) ? 0x3fffffff : bx * TILE + px;
+        out_row = by * TILE + py;
+        y_inv = a.row_begin + by * a.tile_row_stride * TILE + py;
+    } else
 #endif
     tile_pixel(a, x, y_inv, out_row);
 #ifdef RM_DIAG
@@ -156,6 +243,17 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, const G &g) {
     }
 #endif
     *reinterpret_cast<unsigned *>(a.out + (size_t)out_row * a.pitch + (size_t)x * 4) = px;
+#if !defined(RM_DIAG) && !defined(RM_DIAG_TIME)
+    if (a.tile_cost && (threadIdx.x & 63) == 0) {
+        const unsigned ticks = (unsigned)wall_clock64() - cost_t0;
+        if (quarter) {
+            a.tile_cost[cost_at] = ticks;
+        } else {
+            const unsigned as_quarter = (ticks * 5u) >> 3;
+            reinterpret_cast<uint4 *>(a.tile_cost)[cost_at >> 2] = make_uint4(as_quarter, as_quarter, as_quarter, as_quarter);
+        }
+    }
+#endif
 #ifdef RM_DIAG
     diag_lap(DG_PACK);
     __syncthreads();
@@ -851,6 +949,15 @@ struct rm_engine {
     std::vector<float *> d_texels;
     float *d_lightmaps = nullptr;  // [n_patches][3]
     float *d_screen = nullptr;  // u of every column, then v of every row (engine.rs:79-82)
+    // slow tiles in quarters (SplitPlan): the tiles' last lifetimes, and a ring of per-launch plans
+    unsigned *d_tile_cost = nullptr;    // [frame tiles][4]
+    unsigned *d_plan_words = nullptr;   // kPlanRing x (count padded to 64 words + list[kPlanCap])
+    unsigned char *d_plan_flags = nullptr;  // kPlanRing x [frame tiles]
+    unsigned plan_next = 0;
+    int split_threshold = -1;           // ticks; 0 = off; -1 = not read yet (RM_SPLIT_US)
+    bool split_on = true;               // rm_engine_set_tile_splitting
+    const unsigned *last_plan_count = nullptr;  // the count word of the most recent plan (device)
+    unsigned last_plan_cap = 0;                 // and that plan's list length
     unsigned long long *d_stats = nullptr;  // kStatSlots words: RM_STAT_COUNT public ones, the rest for diagnostic builds
     unsigned char *d_frame = nullptr;  // W*H*4, for rm_engine_render
     unsigned char *h_stage = nullptr;  // pinned W*H*4 staging for callers that pass pageable memory
@@ -1373,6 +1480,9 @@ static void engine_free(rm_engine *e) {
     (void)hipFree(e->d_lightmaps);
     (void)hipFree(e->d_stats);
     (void)hipFree(e->d_screen);
+    (void)hipFree(e->d_tile_cost);
+    (void)hipFree(e->d_plan_words);
+    (void)hipFree(e->d_plan_flags);
     (void)hipFree(e->d_view);
     (void)hipFree(e->d_frame);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -1505,6 +1615,11 @@ static RenderArgs make_render_args(rm_engine *e, void *d_out, size_t pitch, int 
     camera_distances(e, a.camera_dist, a.camera_sph);
     a.screen_u = e->d_screen;
     a.screen_v = e->d_screen + e->W;
+    a.plan_count = nullptr;
+    a.plan_list = nullptr;
+    a.plan_flag = nullptr;
+    a.tile_cost = nullptr;
+    a.plan_cap = 0;
     grid = dim3((unsigned)(a.blocks_x * a.blocks_y), 1, 1);
     return a;
 }
@@ -1730,11 +1845,49 @@ int rm_engine_set_camera(rm_engine *e, const float position[3]) {
     return RM_OK;
 }
 
-static void launch_render(rm_engine *e, dim3 grid, const RenderArgs &a) {
-    if (e->tier <= 1 && grid.x >= kDenseLaunchTiles)  // (the small tiers: scene in scalar registers)
-        RM_LAUNCH(render_dense_kernel, e, grid, dim3(BLOCK_THREADS), a);
-    else
-        RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);
+constexpr unsigned kPlanRing = 8;      // plans of launches that may be in flight at once (streams, frames in flight)
+constexpr unsigned kPlanCap = 1024;    // listed tiles per launch at most
+constexpr unsigned kPlanStride = 64 + kPlanCap;  // words per plan: the count in a line of its own, then the list
+
+static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
+    if (e->tier <= 1 && grid.x >= kDenseLaunchTiles) {  // (the small tiers: scene in scalar registers)
+        RM_LAUNCH(render_dense_kernel, e, grid, dim3(BLOCK_THREADS), a0);
+        return RM_OK;
+    }
+    RenderArgs a = a0;
+#if !defined(RM_DIAG) && !defined(RM_DIAG_TIME)
+    // A launch that long launches hide nothing of: its slow tiles go first and in quarters (SplitPlan).
+    if (e->split_threshold < 0) {
+        const char *v = getenv("RM_SPLIT_US");  // threshold for a quarter in microseconds; 0 switches the plans off
+        const double us = v ? atof(v) : kSplitThresholdTicks / 100.0;
+        e->split_threshold = us > 0.0 ? (int)std::min(us * 100.0, 1e9) : 0;
+    }
+    if (e->split_on && e->split_threshold > 0 && grid.x < kDenseLaunchTiles) {
+        const size_t frame_tiles = (size_t)((e->W + TILE - 1) / TILE) * ((e->H + TILE - 1) / TILE + 1);
+        if (!e->d_tile_cost) {
+            HIP_TRY(dev_alloc(&e->d_tile_cost, frame_tiles * 4));
+            HIP_TRY(hipMemsetAsync(e->d_tile_cost, 0, frame_tiles * 4 * sizeof(unsigned), e->stream));
+            HIP_TRY(dev_alloc(&e->d_plan_words, (size_t)kPlanRing * kPlanStride));
+            HIP_TRY(dev_alloc(&e->d_plan_flags, (size_t)kPlanRing * frame_tiles));
+        }
+        const unsigned slot = e->plan_next++ % kPlanRing;
+        unsigned *count = e->d_plan_words + (size_t)slot * kPlanStride, *list = count + 64;
+        unsigned char *flag = e->d_plan_flags + (size_t)slot * frame_tiles;
+        a.tile_cost = e->d_tile_cost;
+        a.plan_cap = std::min<unsigned>(kPlanCap, std::max<unsigned>(16u, grid.x / 16u));
+        HIP_TRY(hipMemsetAsync(count, 0, sizeof(unsigned), e->stream));
+        hipLaunchKernelGGL(split_plan_kernel, dim3((grid.x + 255) / 256), dim3(256), 0, e->stream, a, count, list, flag,
+                           (unsigned)e->split_threshold);
+        a.plan_count = count;
+        e->last_plan_count = count;
+        e->last_plan_cap = a.plan_cap;
+        a.plan_list = list;
+        a.plan_flag = flag;
+        grid = dim3(grid.x + 4u * a.plan_cap, 1, 1);
+    }
+#endif
+    RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);
+    return RM_OK;
 }
 
 int rm_engine_render_rows_device(rm_engine *e, void *d_bgra, size_t pitch_bytes, int row_begin, int row_end) {
@@ -1766,7 +1919,7 @@ int rm_engine_render_rows_device(rm_engine *e, void *d_bgra, size_t pitch_bytes,
         const dim3 grid2((unsigned)std::min<size_t>((size_t)e->two_pass, (capacity + BLOCK_THREADS - 1) / BLOCK_THREADS));
         RM_LAUNCH(render_reflect_kernel, e, grid2, dim3(BLOCK_THREADS), a, q);
     } else
-        launch_render(e, grid, a);
+        if (int rc_ = launch_render(e, grid, a)) return rc_;
     HIP_TRY(hipGetLastError());
     return RM_OK;
 }
@@ -1789,7 +1942,7 @@ int rm_engine_render_strips_device(rm_engine *e, void *d_bgra, size_t pitch_byte
     else if (e->ssaa)
         RM_LAUNCH(render_ssaa_kernel, e, grid, dim3(BLOCK_THREADS), a);
     else
-        launch_render(e, grid, a);
+        if (int rc_ = launch_render(e, grid, a)) return rc_;
     HIP_TRY(hipGetLastError());
     return RM_OK;
 }
@@ -2309,6 +2462,25 @@ int rm_engine_set_refraction(rm_engine *e, int on) {
     if (!e) return fail(RM_ERR_INVALID, "NULL engine");
     e->refraction = on != 0;
     e->view_dirty = true;
+    return RM_OK;
+}
+
+int rm_engine_set_tile_splitting(rm_engine *e, int on) {
+    if (!e) return fail(RM_ERR_INVALID, "NULL engine");
+    e->split_on = on != 0;
+    return RM_OK;
+}
+
+int rm_engine_split_tiles(rm_engine *e, uint32_t *count) {
+    if (!e || !count) return fail(RM_ERR_INVALID, "NULL argument");
+    *count = 0;
+    if (!e->last_plan_count) return RM_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    quiesce_frames_in_flight(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    unsigned n = 0;
+    HIP_TRY(hipMemcpy(&n, e->last_plan_count, sizeof(n), hipMemcpyDeviceToHost));
+    *count = std::min<unsigned>(n, e->last_plan_cap);  // (tiles found slow beyond the list's length were rendered whole)
     return RM_OK;
 }
 

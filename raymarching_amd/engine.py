@@ -266,6 +266,16 @@ class Engine:
     def set_march_cap(self, max_steps):
         _lib.check(self.lib.rm_engine_set_march_cap(self.handle, max_steps), "rm_engine_set_march_cap")
 
+    def set_tile_splitting(self, on):
+        """Slow tiles first and in quarters (small launches; see rm.h): on by default."""
+        _lib.check(self.lib.rm_engine_set_tile_splitting(self.handle, 1 if on else 0), "rm_engine_set_tile_splitting")
+
+    def split_tiles(self):
+        """Tiles the most recent planned launch rendered in quarters (waits for the engine's work)."""
+        n = ctypes.c_uint32(0)
+        _lib.check(self.lib.rm_engine_split_tiles(self.handle, ctypes.byref(n)), "rm_engine_split_tiles")
+        return int(n.value)
+
     def stats(self):
         out = (c_uint64 * _lib.RM_STAT_COUNT)()
         _lib.check(self.lib.rm_engine_get_stats(self.handle, out), "rm_engine_get_stats")

@@ -234,6 +234,71 @@ def test_probe_shade_outside_the_usual_ranges(scene, oracle_lightmaps, intensity
     ora.close()
 
 
+@pytest.mark.parametrize("threshold_us", [None, 5.0, 0.2])
+def test_slow_tiles_in_quarters_render_the_same_frame(scene, oracle_lightmaps, threshold_us, monkeypatch):
+    """Launches planned from the tiles' last timings (slow tiles first, as four waves of 4x4 pixels):
+    every frame equals the one rendered with the plans switched off, for whole frames, row ranges that
+    do not start on a tile boundary, strips, and a camera that has moved since the timings were taken.
+    Thresholds: the default, 5 us (a third of the tiles) and 0.2 us (every tile: the list overflows)."""
+    import torch
+
+    from raymarching_amd import Engine
+
+    if threshold_us is not None:
+        monkeypatch.setenv("RM_SPLIT_US", str(threshold_us))
+    lm, _ = oracle_lightmaps
+    w, h = 1280, 720
+
+    def engine(split):
+        e = Engine(scene, w, h)
+        for i, values in enumerate(lm[-1]):
+            e.set_lightmap(i, values)
+        e.set_tile_splitting(split)
+        return e
+
+    plain, planned = engine(False), engine(True)
+
+    def rows(e, r0, r1):
+        buf = torch.zeros((r1 - r0, w, 4), dtype=torch.uint8, device="cuda")
+        e.render_rows_device(buf.data_ptr(), r0, r1)
+        e.synchronize()
+        return buf
+
+    def strips(e, first, stride, n):
+        buf = torch.zeros((n * 8, w, 4), dtype=torch.uint8, device="cuda")
+        e.render_strips_device(buf.data_ptr(), first, stride, n)
+        e.synchronize()
+        return buf
+
+    split_counts = []
+    first_pose_frame = None
+    for pose in ((0, 0, (0.0, 0.0, 0.0), 0), (35, -20, (0.25, 0.0, 0.5), 1), (-60, 10, (-0.4, 0.1, 0.2), -1)):
+        plain.input(*pose)
+        planned.input(*pose)
+        want = rows(plain, 0, h)
+        for frame in range(3):
+            got = rows(planned, 0, h)
+            assert torch.equal(got, want), (pose, frame)
+            split_counts.append(planned.split_tiles())
+            if first_pose_frame is None:
+                first_pose_frame = got.cpu().numpy()
+        assert torch.equal(rows(planned, 100, 613), want[100:613])
+        got = strips(planned, 1, 3, 30)
+        for k in range(30):
+            r = (1 + 3 * k) * 8
+            assert torch.equal(got[k * 8:(k + 1) * 8], want[r:r + 8]), (pose, k)
+    print(f"threshold {threshold_us}: tiles in quarters per whole-frame launch {split_counts}")
+    assert split_counts[0] == 0  # nothing is known before the first frame
+    assert max(split_counts) > 0
+    if threshold_us == 0.2:
+        assert max(split_counts) == 900  # the cap of this launch: 14400 tiles / 16
+    assert plain.split_tiles() == 0
+    ref = make_oracle(scene, lm[-1]).render(w, h)
+    assert_frames_match(first_pose_frame, ref, "first pose")
+    plain.close()
+    planned.close()
+
+
 def test_headless_host_harness(tmp_path, scene, oracle_lightmaps):
     """The C++ host mirror of main.rs (host/main.cpp) renders the default frame through the C ABI."""
     import os

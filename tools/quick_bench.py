@@ -43,6 +43,10 @@ for r in range(ROUNDS):
         ev1.record()
         torch.cuda.synchronize()
         times[i].append(ev0.elapsed_time(ev1) / FRAMES)
+torch.cuda.synchronize()
+for i, b in enumerate(bufs[1:], 1):  # again after many frames: builds that plan a frame from the last one's timings
+    if not torch.equal(b, bufs[0]):
+        print(f"{libs[i]}: image DIFFERS from {libs[0]} after the timed frames")
 for path, t in zip(libs, times):
     t.sort()
     print(f"{os.path.basename(path):40s} median {t[len(t)//2]:.4f} ms  min {t[0]:.4f} ms  -> {W*H/t[len(t)//2]/1e3:.0f} Mrays/s")
