@@ -285,8 +285,9 @@ int rm_engine_set_march_cap(rm_engine *engine, int max_steps);
  * launch of fewer than 65536 tiles lasts as long as its slowest wave, so the frame kernel renders
  * the tiles that took longest the last time they were rendered first and as four waves of 4x4
  * pixels each (a quarter's pixels drift apart less between reflection levels: 0.6 of the time).
- * On by default (RM_SPLIT_US in the environment sets the threshold for a quarter in microseconds,
- * 0 switches it off).  A caller that keeps several launches of one engine in flight, where the
+ * A tile counts as slow at 45 us for a quarter and at least three times the mean tile of the
+ * engine's previous planned launch (RM_SPLIT_US and RM_SPLIT_TIMES_MEAN in the environment set the
+ * two, RM_SPLIT_US=0 switches the plans off).  On by default.  A caller that keeps several launches of one engine in flight, where the
  * machine is busy anyway and the quarters' idle lanes cost throughput, switches it off
  * (rm_group_create does for more than one frame in flight).  rm_engine_split_tiles waits for the
  * engine's work and reports how many tiles the most recent planned launch rendered in quarters. */

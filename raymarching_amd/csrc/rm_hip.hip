@@ -75,15 +75,36 @@ constexpr unsigned kSplitThresholdTicks = 4500;  // 45 us for a quarter, 72 us f
 __device__ __forceinline__ unsigned frame_tile_of(const RenderArgs &a, int bx, int by) {
     return (unsigned)((a.row_begin + by * a.tile_row_stride * TILE) / TILE) * (unsigned)a.blocks_x + (unsigned)bx;
 }
+// `count`: word 0 = slow tiles found, word 1 = sum of the launch's tile costs / 16, word 2 = tiles
+// summed (all zero when the kernel starts).  `previous` = the same words of the engine's plan before
+// this one: a tile counts as slow only at `times_mean` (3) times the mean cost of that launch, so that
+// a scene in which every tile is slow is not rendered in quarters throughout.
 __global__ __launch_bounds__(256) void split_plan_kernel(const RenderArgs a, unsigned *count, unsigned *list, unsigned char *flag,
-                                                         unsigned threshold) {
+                                                         unsigned threshold, const unsigned *previous, unsigned times_mean) {
     const unsigned t = blockIdx.x * 256 + threadIdx.x;
     const unsigned n = (unsigned)(a.blocks_x * a.blocks_y);
+    if (previous[2] > 0) threshold = max(threshold, times_mean * (unsigned)(((unsigned long long)previous[1] * 16ull) / previous[2]));
     bool slow = false;
+    unsigned cost = 0;
     if (t < n) {
         const int by = a.blocks_y - 1 - (int)(t / (unsigned)a.blocks_x), bx = (int)(t % (unsigned)a.blocks_x);
         const uint4 c = reinterpret_cast<const uint4 *>(a.tile_cost)[frame_tile_of(a, bx, by)];
-        slow = max(max(c.x, c.y), max(c.z, c.w)) >= threshold;
+        cost = max(max(c.x, c.y), max(c.z, c.w));
+        slow = cost >= threshold;
+    }
+    {   // the launch's mean cost, for the next plan: one atomic pair per workgroup
+        __shared__ unsigned sum16, tiles;
+        if (threadIdx.x == 0) sum16 = tiles = 0;
+        __syncthreads();
+        if (t < n) {
+            atomicAdd(&sum16, min(cost, 1u << 20) >> 4);
+            atomicAdd(&tiles, 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(count + 1, sum16);
+            atomicAdd(count + 2, tiles);
+        }
     }
     // one atomic per wave that has a slow tile
     const unsigned long long slow_lanes = __builtin_amdgcn_ballot_w64(slow);
@@ -956,6 +977,7 @@ struct rm_engine {
     unsigned plan_next = 0;
     int split_threshold = -1;           // ticks; 0 = off; -1 = not read yet (RM_SPLIT_US)
     bool split_on = true;               // rm_engine_set_tile_splitting
+    unsigned split_times_mean = 3;      // ... and at least this many times the last launch's mean tile cost
     const unsigned *last_plan_count = nullptr;  // the count word of the most recent plan (device)
     unsigned last_plan_cap = 0;                 // and that plan's list length
     unsigned long long *d_stats = nullptr;  // kStatSlots words: RM_STAT_COUNT public ones, the rest for diagnostic builds
@@ -1861,6 +1883,8 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         const char *v = getenv("RM_SPLIT_US");  // threshold for a quarter in microseconds; 0 switches the plans off
         const double us = v ? atof(v) : kSplitThresholdTicks / 100.0;
         e->split_threshold = us > 0.0 ? (int)std::min(us * 100.0, 1e9) : 0;
+        const char *m = getenv("RM_SPLIT_TIMES_MEAN");  // (0 = the absolute threshold alone)
+        if (m) e->split_times_mean = (unsigned)std::min(std::max(atoi(m), 0), 1000);
     }
     if (e->split_on && e->split_threshold > 0 && grid.x < kDenseLaunchTiles) {
         const size_t frame_tiles = (size_t)((e->W + TILE - 1) / TILE) * ((e->H + TILE - 1) / TILE + 1);
@@ -1868,6 +1892,7 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
             HIP_TRY(dev_alloc(&e->d_tile_cost, frame_tiles * 4));
             HIP_TRY(hipMemsetAsync(e->d_tile_cost, 0, frame_tiles * 4 * sizeof(unsigned), e->stream));
             HIP_TRY(dev_alloc(&e->d_plan_words, (size_t)kPlanRing * kPlanStride));
+            HIP_TRY(hipMemsetAsync(e->d_plan_words, 0, (size_t)kPlanRing * kPlanStride * sizeof(unsigned), e->stream));
             HIP_TRY(dev_alloc(&e->d_plan_flags, (size_t)kPlanRing * frame_tiles));
         }
         const unsigned slot = e->plan_next++ % kPlanRing;
@@ -1875,9 +1900,10 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         unsigned char *flag = e->d_plan_flags + (size_t)slot * frame_tiles;
         a.tile_cost = e->d_tile_cost;
         a.plan_cap = std::min<unsigned>(kPlanCap, std::max<unsigned>(16u, grid.x / 16u));
-        HIP_TRY(hipMemsetAsync(count, 0, sizeof(unsigned), e->stream));
+        const unsigned *previous = e->last_plan_count ? e->last_plan_count : count + 8;  // (the first plan: words that stay zero)
+        HIP_TRY(hipMemsetAsync(count, 0, 4 * sizeof(unsigned), e->stream));
         hipLaunchKernelGGL(split_plan_kernel, dim3((grid.x + 255) / 256), dim3(256), 0, e->stream, a, count, list, flag,
-                           (unsigned)e->split_threshold);
+                           (unsigned)e->split_threshold, previous, e->split_times_mean);
         a.plan_count = count;
         e->last_plan_count = count;
         e->last_plan_cap = a.plan_cap;

@@ -246,6 +246,7 @@ def test_slow_tiles_in_quarters_render_the_same_frame(scene, oracle_lightmaps, t
 
     if threshold_us is not None:
         monkeypatch.setenv("RM_SPLIT_US", str(threshold_us))
+        monkeypatch.setenv("RM_SPLIT_TIMES_MEAN", "0")  # the absolute threshold alone decides
     lm, _ = oracle_lightmaps
     w, h = 1280, 720
 
