@@ -75,36 +75,30 @@ constexpr unsigned kSplitThresholdTicks = 4500;  // 45 us for a quarter, 72 us f
 __device__ __forceinline__ unsigned frame_tile_of(const RenderArgs &a, int bx, int by) {
     return (unsigned)((a.row_begin + by * a.tile_row_stride * TILE) / TILE) * (unsigned)a.blocks_x + (unsigned)bx;
 }
-// `count`: word 0 = slow tiles found, word 1 = sum of the launch's tile costs / 16, word 2 = tiles
-// summed (all zero when the kernel starts).  `previous` = the same words of the engine's plan before
-// this one: a tile counts as slow only at `times_mean` (3) times the mean cost of that launch, so that
-// a scene in which every tile is slow is not rendered in quarters throughout.
+// `count`: word 0 = slow tiles found (zero when the kernel starts), word 1 = the mean cost of a sample
+// of the launch's tiles.  `previous` = the same words of the engine's plan before this one: a tile
+// counts as slow only at `times_mean` (3) times that launch's mean, so that a scene in which every
+// tile is slow is not rendered in quarters throughout.
+__device__ __forceinline__ unsigned tile_cost_of(const RenderArgs &a, unsigned t) {
+    const int by = a.blocks_y - 1 - (int)(t / (unsigned)a.blocks_x), bx = (int)(t % (unsigned)a.blocks_x);
+    const uint4 c = reinterpret_cast<const uint4 *>(a.tile_cost)[frame_tile_of(a, bx, by)];
+    return max(max(c.x, c.y), max(c.z, c.w));
+}
 __global__ __launch_bounds__(256) void split_plan_kernel(const RenderArgs a, unsigned *count, unsigned *list, unsigned char *flag,
                                                          unsigned threshold, const unsigned *previous, unsigned times_mean) {
     const unsigned t = blockIdx.x * 256 + threadIdx.x;
     const unsigned n = (unsigned)(a.blocks_x * a.blocks_y);
-    if (previous[2] > 0) threshold = max(threshold, times_mean * (unsigned)(((unsigned long long)previous[1] * 16ull) / previous[2]));
-    bool slow = false;
-    unsigned cost = 0;
-    if (t < n) {
-        const int by = a.blocks_y - 1 - (int)(t / (unsigned)a.blocks_x), bx = (int)(t % (unsigned)a.blocks_x);
-        const uint4 c = reinterpret_cast<const uint4 *>(a.tile_cost)[frame_tile_of(a, bx, by)];
-        cost = max(max(c.x, c.y), max(c.z, c.w));
-        slow = cost >= threshold;
-    }
-    {   // the launch's mean cost, for the next plan: one atomic pair per workgroup
-        __shared__ unsigned sum16, tiles;
-        if (threadIdx.x == 0) sum16 = tiles = 0;
+    threshold = max(threshold, times_mean * previous[1]);
+    bool slow = t < n && tile_cost_of(a, t) >= threshold;
+    if (blockIdx.x == 0) {
+        // the mean over 256 tiles spread evenly through the launch, for the next plan
+        __shared__ unsigned sum16;
+        if (threadIdx.x == 0) sum16 = 0;
         __syncthreads();
-        if (t < n) {
-            atomicAdd(&sum16, min(cost, 1u << 20) >> 4);
-            atomicAdd(&tiles, 1u);
-        }
+        const unsigned sample = (unsigned)(((unsigned long long)threadIdx.x * n) >> 8);
+        atomicAdd(&sum16, min(tile_cost_of(a, sample), 1u << 20) >> 4);
         __syncthreads();
-        if (threadIdx.x == 0) {
-            atomicAdd(count + 1, sum16);
-            atomicAdd(count + 2, tiles);
-        }
+        if (threadIdx.x == 0) count[1] = sum16 >> 4;  // (/ 256 tiles * 16)
     }
     // one atomic per wave that has a slow tile
     const unsigned long long slow_lanes = __builtin_amdgcn_ballot_w64(slow);
@@ -1901,7 +1895,7 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         a.tile_cost = e->d_tile_cost;
         a.plan_cap = std::min<unsigned>(kPlanCap, std::max<unsigned>(16u, grid.x / 16u));
         const unsigned *previous = e->last_plan_count ? e->last_plan_count : count + 8;  // (the first plan: words that stay zero)
-        HIP_TRY(hipMemsetAsync(count, 0, 4 * sizeof(unsigned), e->stream));
+        HIP_TRY(hipMemsetAsync(count, 0, sizeof(unsigned), e->stream));
         hipLaunchKernelGGL(split_plan_kernel, dim3((grid.x + 255) / 256), dim3(256), 0, e->stream, a, count, list, flag,
                            (unsigned)e->split_threshold, previous, e->split_times_mean);
         a.plan_count = count;
