@@ -289,7 +289,8 @@ int rm_engine_set_march_cap(rm_engine *engine, int max_steps);
  * engine's previous planned launch (RM_SPLIT_US and RM_SPLIT_TIMES_MEAN in the environment set the
  * two, RM_SPLIT_US=0 switches the plans off).  On by default.  A caller that keeps several launches of one engine in flight, where the
  * machine is busy anyway and the quarters' idle lanes cost throughput, switches it off
- * (rm_group_create does for more than one frame in flight).  rm_engine_split_tiles waits for the
+ * (rm_group_create does for more than one frame in flight, unless a rank's share is below 20000
+ * tiles, where the plans still pay).  rm_engine_split_tiles waits for the
  * engine's work and reports how many tiles the most recent planned launch rendered in quarters. */
 int rm_engine_set_tile_splitting(rm_engine *engine, int on);
 int rm_engine_split_tiles(rm_engine *engine, uint32_t *count);

@@ -174,11 +174,15 @@ static rm_group *group_build(rm_engine *e, int rank, int world, int frames_in_fl
     g->rank = rank;
     g->world = world;
     g->in_flight = frames_in_flight;
-    // with several frames in flight the machine is busy while a frame's slow tiles finish: the
-    // quarter waves of rm_engine_set_tile_splitting would only cost throughput
-    if (frames_in_flight > 1) e->split_on = false;
     const int strips = (e->H + RM_STRIP_ROWS - 1) / RM_STRIP_ROWS;
     g->strips_per_rank = (strips + world - 1) / world;
+    // With several frames in flight the machine is busy while a frame's slow tiles finish, and the
+    // quarter waves of rm_engine_set_tile_splitting cost throughput - unless a rank's share is so
+    // small that even three of them leave the machine waiting for their slow tiles (measured on
+    // shares of the 3840x2160 frame, two or three in flight: a half and a quarter - 64800 and
+    // 32400 tiles - are 10 % slower with the plans, an eighth - 16200 tiles - 6-23 % faster).
+    const long share_tiles = (long)g->strips_per_rank * ((e->W + TILE - 1) / TILE);
+    if (frames_in_flight > 1 && share_tiles > 20000) e->split_on = false;
     g->band_pixels = (size_t)g->strips_per_rank * RM_STRIP_ROWS * e->W;
     g->packed = e->W % 4 == 0 && e->H <= 65535;
     const size_t wire = g->packed ? 3 : 4;
