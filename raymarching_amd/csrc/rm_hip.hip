@@ -56,6 +56,7 @@ struct RenderArgs {
     const unsigned char *plan_flag;    // [tiles of the launch]: 1 = on the list
     unsigned *tile_cost;               // [tiles of the frame][4]: how long each quarter last took, 10 ns ticks
     unsigned plan_cap;                 // the first 4 * plan_cap workgroups are the quarter waves
+    unsigned cost_tiles;               // entries of tile_cost
 };
 
 // Slow tiles in quarters.  A launch that does not fill the machine many times over lasts as long as
@@ -73,7 +74,8 @@ struct RenderArgs {
 // only.  The pixels do not depend on which wave renders them.
 constexpr unsigned kSplitThresholdTicks = 4500;  // 45 us for a quarter, 72 us for the whole tile (30-60 us measured alike)
 __device__ __forceinline__ unsigned frame_tile_of(const RenderArgs &a, int bx, int by) {
-    return (unsigned)((a.row_begin + by * a.tile_row_stride * TILE) / TILE) * (unsigned)a.blocks_x + (unsigned)bx;
+    // (a launch of strips may name strips below the frame's last row: they share the last entry)
+    return min((unsigned)((a.row_begin + by * a.tile_row_stride * TILE) / TILE) * (unsigned)a.blocks_x + (unsigned)bx, a.cost_tiles - 1u);
 }
 // `count`: word 0 = slow tiles found (zero when the kernel starts), word 1 = the mean cost of a sample
 // of the launch's tiles.  `previous` = the same words of the engine's plan before this one: a tile
@@ -1636,6 +1638,7 @@ static RenderArgs make_render_args(rm_engine *e, void *d_out, size_t pitch, int 
     a.plan_flag = nullptr;
     a.tile_cost = nullptr;
     a.plan_cap = 0;
+    a.cost_tiles = 0;
     grid = dim3((unsigned)(a.blocks_x * a.blocks_y), 1, 1);
     return a;
 }
@@ -1893,6 +1896,7 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         unsigned *count = e->d_plan_words + (size_t)slot * kPlanStride, *list = count + 64;
         unsigned char *flag = e->d_plan_flags + (size_t)slot * frame_tiles;
         a.tile_cost = e->d_tile_cost;
+        a.cost_tiles = (unsigned)frame_tiles;
         a.plan_cap = std::min<unsigned>(kPlanCap, std::max<unsigned>(16u, grid.x / 16u));
         const unsigned *previous = e->last_plan_count ? e->last_plan_count : count + 8;  // (the first plan: words that stay zero)
         HIP_TRY(hipMemsetAsync(count, 0, sizeof(unsigned), e->stream));

@@ -288,6 +288,11 @@ def test_slow_tiles_in_quarters_render_the_same_frame(scene, oracle_lightmaps, t
         for k in range(30):
             r = (1 + 3 * k) * 8
             assert torch.equal(got[k * 8:(k + 1) * 8], want[r:r + 8]), (pose, k)
+        got = strips(planned, 2, 4, 23)  # the last strip named (90) lies below the frame's 90 strips
+        for k in range(22):
+            r = (2 + 4 * k) * 8
+            assert torch.equal(got[k * 8:(k + 1) * 8], want[r:r + 8]), (pose, k)
+        assert int(got[22 * 8:].max()) == 0
     print(f"threshold {threshold_us}: tiles in quarters per whole-frame launch {split_counts}")
     assert split_counts[0] == 0  # nothing is known before the first frame
     assert max(split_counts) > 0
