@@ -1883,8 +1883,10 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         const char *m = getenv("RM_SPLIT_TIMES_MEAN");  // (0 = the absolute threshold alone)
         if (m) e->split_times_mean = (unsigned)std::min(std::max(atoi(m), 0), 1000);
     }
-    if (e->split_on && e->split_threshold > 0 && grid.x < kDenseLaunchTiles) {
-        const size_t frame_tiles = (size_t)((e->W + TILE - 1) / TILE) * ((e->H + TILE - 1) / TILE + 1);
+    const size_t frame_tiles = (size_t)((e->W + TILE - 1) / TILE) * ((e->H + TILE - 1) / TILE + 1);
+    // (a launch that names more tiles than the frame has - strips far below it - is not planned: the
+    // plan's flags are one per frame tile)
+    if (e->split_on && e->split_threshold > 0 && grid.x < kDenseLaunchTiles && grid.x <= frame_tiles) {
         if (!e->d_tile_cost) {
             HIP_TRY(dev_alloc(&e->d_tile_cost, frame_tiles * 4));
             HIP_TRY(hipMemsetAsync(e->d_tile_cost, 0, frame_tiles * 4 * sizeof(unsigned), e->stream));
