@@ -281,10 +281,11 @@ int rm_engine_set_refraction(rm_engine *engine, int on);
  * ends by itself after at most 50/0.001 steps).  Cut marches are counted. */
 int rm_engine_set_march_cap(rm_engine *engine, int max_steps);
 
-/* Slow tiles in quarters (no counterpart in the reference; the pixels do not depend on it).  A
+/* Slow tiles first (no counterpart in the reference; the pixels do not depend on it).  A
  * launch of fewer than 65536 tiles lasts as long as its slowest wave, so the frame kernel renders
  * the tiles that took longest the last time they were rendered first and as four waves of 4x4
  * pixels each (a quarter's pixels drift apart less between reflection levels: 0.6 of the time).
+ * A longer launch of a scene with a spatial index only hands its slow tiles out first, whole.
  * A tile counts as slow at 45 us for a quarter and at least three times the mean tile of the
  * engine's previous planned launch (RM_SPLIT_US and RM_SPLIT_TIMES_MEAN in the environment set the
  * two, RM_SPLIT_US=0 switches the plans off).  On by default.  A caller that keeps several launches of one engine in flight, where the

@@ -55,7 +55,8 @@ struct RenderArgs {
     const unsigned *plan_list;         // launch-local numbers of the tiles rendered by four waves
     const unsigned char *plan_flag;    // [tiles of the launch]: 1 = on the list
     unsigned *tile_cost;               // [tiles of the frame][4]: how long each quarter last took, 10 ns ticks
-    unsigned plan_cap;                 // the first 4 * plan_cap workgroups are the quarter waves
+    unsigned plan_cap;                 // the first plan_per * plan_cap workgroups render the listed tiles
+    unsigned plan_per;                 // 4: a listed tile is rendered by four waves, a quarter each; 1: by one wave, only early
     unsigned cost_tiles;               // entries of tile_cost
 };
 
@@ -166,12 +167,12 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, const G &g) {
         cost_t0 = (unsigned)wall_clock64();
         unsigned tile = blockIdx.x;
         if (a.plan_count) {
-            const unsigned first_whole = 4u * a.plan_cap;
+            const unsigned first_whole = a.plan_per * a.plan_cap;
             if (blockIdx.x < first_whole) {
                 const unsigned listed = min(*a.plan_count, a.plan_cap);
-                if (blockIdx.x >= 4u * listed) return;
-                tile = a.plan_list[blockIdx.x >> 2];
-                quarter = true;
+                if (blockIdx.x >= a.plan_per * listed) return;
+                quarter = a.plan_per == 4;
+                tile = a.plan_list[quarter ? blockIdx.x >> 2 : blockIdx.x];
             } else {
                 tile = blockIdx.x - first_whole;
                 if (a.plan_flag[tile]) return;
@@ -1638,6 +1639,7 @@ static RenderArgs make_render_args(rm_engine *e, void *d_out, size_t pitch, int 
     a.plan_flag = nullptr;
     a.tile_cost = nullptr;
     a.plan_cap = 0;
+    a.plan_per = 4;
     a.cost_tiles = 0;
     grid = dim3((unsigned)(a.blocks_x * a.blocks_y), 1, 1);
     return a;
@@ -1865,11 +1867,15 @@ int rm_engine_set_camera(rm_engine *e, const float position[3]) {
 }
 
 constexpr unsigned kPlanRing = 8;      // plans of launches that may be in flight at once (streams, frames in flight)
-constexpr unsigned kPlanCap = 1024;    // listed tiles per launch at most
-constexpr unsigned kPlanStride = 64 + kPlanCap;  // words per plan: the count in a line of its own, then the list
+constexpr unsigned kPlanCap = 1024;    // tiles listed for quarters per launch at most
+constexpr unsigned kPlanCapEarly = 16384;  // ... listed to go first in a long launch
+constexpr unsigned kPlanStride = 64 + kPlanCapEarly;  // words per plan: the count in a line of its own, then the list
 
 static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
-    if (e->tier <= 1 && grid.x >= kDenseLaunchTiles) {  // (the small tiers: scene in scalar registers)
+    const bool long_launch = grid.x >= kDenseLaunchTiles;
+    if (e->tier <= 1 && long_launch) {
+        // the small tiers (scene in scalar registers) have the 8-wave build for this, and no tail worth a
+        // plan: the 3840x2160 frame takes 0.284 ms with its slow tiles first against 0.283 ms without
         RM_LAUNCH(render_dense_kernel, e, grid, dim3(BLOCK_THREADS), a0);
         return RM_OK;
     }
@@ -1886,7 +1892,10 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
     const size_t frame_tiles = (size_t)((e->W + TILE - 1) / TILE) * ((e->H + TILE - 1) / TILE + 1);
     // (a launch that names more tiles than the frame has - strips far below it - is not planned: the
     // plan's flags are one per frame tile)
-    if (e->split_on && e->split_threshold > 0 && grid.x < kDenseLaunchTiles && grid.x <= frame_tiles) {
+    // A long launch of a large scene keeps the machine full but ends with the slow tiles of the rows
+    // handed out last (the 7680x4320 stress frame: 99 % of the waves have ended after 14.2 of 15.8 ms):
+    // its plan lists the slow tiles to go first, whole - quarters would cost throughput there.
+    if (e->split_on && e->split_threshold > 0 && grid.x <= frame_tiles) {
         if (!e->d_tile_cost) {
             HIP_TRY(dev_alloc(&e->d_tile_cost, frame_tiles * 4));
             HIP_TRY(hipMemsetAsync(e->d_tile_cost, 0, frame_tiles * 4 * sizeof(unsigned), e->stream));
@@ -1899,7 +1908,8 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         unsigned char *flag = e->d_plan_flags + (size_t)slot * frame_tiles;
         a.tile_cost = e->d_tile_cost;
         a.cost_tiles = (unsigned)frame_tiles;
-        a.plan_cap = std::min<unsigned>(kPlanCap, std::max<unsigned>(16u, grid.x / 16u));
+        a.plan_per = long_launch ? 1u : 4u;
+        a.plan_cap = std::min<unsigned>(long_launch ? kPlanCapEarly : kPlanCap, std::max<unsigned>(16u, grid.x / 16u));
         const unsigned *previous = e->last_plan_count ? e->last_plan_count : count + 8;  // (the first plan: words that stay zero)
         HIP_TRY(hipMemsetAsync(count, 0, sizeof(unsigned), e->stream));
         hipLaunchKernelGGL(split_plan_kernel, dim3((grid.x + 255) / 256), dim3(256), 0, e->stream, a, count, list, flag,
@@ -1909,7 +1919,7 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         e->last_plan_cap = a.plan_cap;
         a.plan_list = list;
         a.plan_flag = flag;
-        grid = dim3(grid.x + 4u * a.plan_cap, 1, 1);
+        grid = dim3(grid.x + a.plan_per * a.plan_cap, 1, 1);
     }
 #endif
     RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);

@@ -12,7 +12,13 @@ _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from raymarching_amd.engine import Engine
 
 W, H = int(os.environ.get("RM_W", 3840)), int(os.environ.get("RM_H", 2160))
-e = Engine(default_scene(), W, H)
+if os.environ.get("RM_STRESS"):  # the smooth-union stress scene (bench.py --workload stress) instead
+    from raymarching_amd.scene import stress_scene
+
+    e = Engine(stress_scene(250, boxes=True, smooth_union=0.08), W, H)
+    e.set_march_cap(1024)
+else:
+    e = Engine(default_scene(), W, H)
 e.compute_lightmaps(4)
 only = os.environ.get("RM_ONLY_STRIP")  # render just this 8-row strip: every wave alone on its SIMD
 if only is not None:
