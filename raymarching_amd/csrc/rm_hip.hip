@@ -89,8 +89,10 @@ __device__ __forceinline__ unsigned tile_cost_of(const RenderArgs &a, unsigned t
 }
 __global__ __launch_bounds__(256) void split_plan_kernel(const RenderArgs a, unsigned *count, unsigned *list, unsigned char *flag,
                                                          unsigned threshold, const unsigned *previous, unsigned times_mean) {
-    const unsigned t = blockIdx.x * 256 + threadIdx.x;
+    // (tiles are looked at last-handed-out first: if the list overflows, the slow tiles left off it are
+    // those the usual order starts early anyway)
     const unsigned n = (unsigned)(a.blocks_x * a.blocks_y);
+    const unsigned t = n - 1u - (blockIdx.x * 256 + threadIdx.x);  // (wraps to >= n beyond the launch)
     threshold = max(threshold, times_mean * previous[1]);
     bool slow = t < n && tile_cost_of(a, t) >= threshold;
     if (blockIdx.x == 0) {
@@ -160,7 +162,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, const G &g) {
     const unsigned long long diag_t0 = wall_clock64();
     const unsigned long long diag_c0 = __builtin_readcyclecounter();
 #endif
-#if !defined(RM_DIAG) && !defined(RM_DIAG_TIME)
+#if !defined(RM_DIAG)
     unsigned cost_at = 0, cost_t0 = 0;
     bool quarter = false;
     if (a.tile_cost) {  // (the same in every wave of the launch)
@@ -261,7 +263,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, const G &g) {
     }
 #endif
     *reinterpret_cast<unsigned *>(a.out + (size_t)out_row * a.pitch + (size_t)x * 4) = px;
-#if !defined(RM_DIAG) && !defined(RM_DIAG_TIME)
+#if !defined(RM_DIAG)
     if (a.tile_cost && (threadIdx.x & 63) == 0) {
         const unsigned ticks = (unsigned)wall_clock64() - cost_t0;
         if (quarter) {
@@ -975,6 +977,7 @@ struct rm_engine {
     int split_threshold = -1;           // ticks; 0 = off; -1 = not read yet (RM_SPLIT_US)
     bool split_on = true;               // rm_engine_set_tile_splitting
     unsigned split_times_mean = 3;      // ... and at least this many times the last launch's mean tile cost
+    unsigned early_times_mean = 2;      // the same for the tiles a long launch hands out first (RM_EARLY_TIMES_MEAN)
     const unsigned *last_plan_count = nullptr;  // the count word of the most recent plan (device)
     unsigned last_plan_cap = 0;                 // and that plan's list length
     unsigned long long *d_stats = nullptr;  // kStatSlots words: RM_STAT_COUNT public ones, the rest for diagnostic builds
@@ -1868,7 +1871,7 @@ int rm_engine_set_camera(rm_engine *e, const float position[3]) {
 
 constexpr unsigned kPlanRing = 8;      // plans of launches that may be in flight at once (streams, frames in flight)
 constexpr unsigned kPlanCap = 1024;    // tiles listed for quarters per launch at most
-constexpr unsigned kPlanCapEarly = 16384;  // ... listed to go first in a long launch
+constexpr unsigned kPlanCapEarly = 65536;  // ... listed to go first in a long launch
 constexpr unsigned kPlanStride = 64 + kPlanCapEarly;  // words per plan: the count in a line of its own, then the list
 
 static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
@@ -1880,7 +1883,7 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         return RM_OK;
     }
     RenderArgs a = a0;
-#if !defined(RM_DIAG) && !defined(RM_DIAG_TIME)
+#if !defined(RM_DIAG)
     // A launch that long launches hide nothing of: its slow tiles go first and in quarters (SplitPlan).
     if (e->split_threshold < 0) {
         const char *v = getenv("RM_SPLIT_US");  // threshold for a quarter in microseconds; 0 switches the plans off
@@ -1888,6 +1891,8 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         e->split_threshold = us > 0.0 ? (int)std::min(us * 100.0, 1e9) : 0;
         const char *m = getenv("RM_SPLIT_TIMES_MEAN");  // (0 = the absolute threshold alone)
         if (m) e->split_times_mean = (unsigned)std::min(std::max(atoi(m), 0), 1000);
+        const char *m2 = getenv("RM_EARLY_TIMES_MEAN");
+        if (m2) e->early_times_mean = (unsigned)std::min(std::max(atoi(m2), 0), 1000);
     }
     const size_t frame_tiles = (size_t)((e->W + TILE - 1) / TILE) * ((e->H + TILE - 1) / TILE + 1);
     // (a launch that names more tiles than the frame has - strips far below it - is not planned: the
@@ -1908,12 +1913,16 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         unsigned char *flag = e->d_plan_flags + (size_t)slot * frame_tiles;
         a.tile_cost = e->d_tile_cost;
         a.cost_tiles = (unsigned)frame_tiles;
+#ifdef RM_DIAG_TIME
+        a.plan_per = 1u;  // (the timeline build marks a tile's first pixels: whole tiles only)
+#else
         a.plan_per = long_launch ? 1u : 4u;
+#endif
         a.plan_cap = std::min<unsigned>(long_launch ? kPlanCapEarly : kPlanCap, std::max<unsigned>(16u, grid.x / 16u));
         const unsigned *previous = e->last_plan_count ? e->last_plan_count : count + 8;  // (the first plan: words that stay zero)
         HIP_TRY(hipMemsetAsync(count, 0, sizeof(unsigned), e->stream));
         hipLaunchKernelGGL(split_plan_kernel, dim3((grid.x + 255) / 256), dim3(256), 0, e->stream, a, count, list, flag,
-                           (unsigned)e->split_threshold, previous, e->split_times_mean);
+                           (unsigned)e->split_threshold, previous, long_launch ? e->early_times_mean : e->split_times_mean);
         a.plan_count = count;
         e->last_plan_count = count;
         e->last_plan_cap = a.plan_cap;

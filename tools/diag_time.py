@@ -35,9 +35,10 @@ else:
     # large frame in row bands)
     buf = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
     e.input(0, 0, (0, 0, 0), 0)
-    for _ in range(2):
+    for _ in range(int(os.environ.get("RM_FRAMES", 2))):  # (a launch may be planned from the last one's timings)
         e.render_rows_device(buf.data_ptr(), 0, H)
     e.synchronize()
+    print(f"tiles listed by the last launch's plan: {e.split_tiles()}")
     img = buf.cpu().numpy()
 px = img.view(np.uint32).reshape(H, W)
 t0 = px[0::8, 0::8].astype(np.int64)
