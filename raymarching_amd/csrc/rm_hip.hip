@@ -155,7 +155,9 @@ template <>
 struct MinWaves<GroupedLarge> {
     static constexpr int value = 7;
 };
-template <class G>
+// PLANS = false compiles the kernel without the plan and cost-table code (the 8-wave build, whose
+// launches are never planned, has no registers to spare for it).
+template <class G, bool PLANS = true>
 __device__ __forceinline__ void render_tile(const RenderArgs &a, const G &g) {
     int x, y_inv, out_row;
 #ifdef RM_DIAG_TIME
@@ -165,7 +167,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, const G &g) {
 #if !defined(RM_DIAG)
     unsigned cost_at = 0, cost_t0 = 0;
     bool quarter = false;
-    if (a.tile_cost) {  // (the same in every wave of the launch)
+    if (PLANS && a.tile_cost) {  // (the same in every wave of the launch)
         cost_t0 = (unsigned)wall_clock64();
         unsigned tile = blockIdx.x;
         if (a.plan_count) {
@@ -264,7 +266,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, const G &g) {
 #endif
     *reinterpret_cast<unsigned *>(a.out + (size_t)out_row * a.pitch + (size_t)x * 4) = px;
 #if !defined(RM_DIAG)
-    if (a.tile_cost && (threadIdx.x & 63) == 0) {
+    if (PLANS && a.tile_cost && (threadIdx.x & 63) == 0) {
         const unsigned ticks = (unsigned)wall_clock64() - cost_t0;
         if (quarter) {
             a.tile_cost[cost_at] = ticks;
@@ -313,7 +315,7 @@ struct MinWavesDense<GroupedLarge> {
 };
 template <class G>
 __global__ __launch_bounds__(BLOCK_THREADS, MinWavesDense<G>::value) void render_dense_kernel(const RenderArgs a, const G g) {
-    render_tile(a, g);
+    render_tile<G, false>(a, g);
 }
 constexpr unsigned kDenseLaunchTiles = 65536;  // between 1920x1080 (32400 tiles) and 3840x2160 (129600)
 
