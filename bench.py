@@ -534,7 +534,7 @@ def main():
                 "kernel": "render_dense_kernel" if ((W + 7) // 8) * ((r1 - r0 + 7) // 8) >= 65536 and not args.ssaa and not args.refraction else "render_kernel",
                 "kernel_ms": kernel_ms,
                 # a launch of fewer than 65536 tiles with one frame in flight is planned (slow tiles first and in
-                # quarters): the events then also span the plan's 4-byte memset and its 5 us kernel
+                # quarters): the events then also span the plan's 5 us kernel
                 "kernel_ms_spans_the_launch_plan": bool(((W + 7) // 8) * ((r1 - r0 + 7) // 8) < 65536 and in_flight == 1 and not args.ssaa and not args.refraction and not gathering),
                 "algorithmic_flops_per_launch": int(flops * band_share),
                 "note": "FP32 vector ALU bound (no MFMA, HBM traffic is 4 B per ray); strict IEEE parity forbids FMA contraction",

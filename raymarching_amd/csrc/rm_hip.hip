@@ -79,7 +79,9 @@ __device__ __forceinline__ unsigned frame_tile_of(const RenderArgs &a, int bx, i
     return min((unsigned)((a.row_begin + by * a.tile_row_stride * TILE) / TILE) * (unsigned)a.blocks_x + (unsigned)bx, a.cost_tiles - 1u);
 }
 // `count`: word 0 = slow tiles found (zero when the kernel starts), word 1 = the mean cost of a sample
-// of the launch's tiles.  `previous` = the same words of the engine's plan before this one: a tile
+// of the launch's tiles.  `count_next` = the count word of the stream's next plan, cleared here: a
+// stream's plans alternate between two sets of words, and the set not in use was last read by the
+// launch before this one, which has finished (same stream).  `previous` = the same words of the engine's plan before this one: a tile
 // counts as slow only at `times_mean` (3) times that launch's mean, so that a scene in which every
 // tile is slow is not rendered in quarters throughout.
 __device__ __forceinline__ unsigned tile_cost_of(const RenderArgs &a, unsigned t) {
@@ -88,7 +90,8 @@ __device__ __forceinline__ unsigned tile_cost_of(const RenderArgs &a, unsigned t
     return max(max(c.x, c.y), max(c.z, c.w));
 }
 __global__ __launch_bounds__(256) void split_plan_kernel(const RenderArgs a, unsigned *count, unsigned *list, unsigned char *flag,
-                                                         unsigned threshold, const unsigned *previous, unsigned times_mean) {
+                                                         unsigned threshold, const unsigned *previous, unsigned times_mean,
+                                                         unsigned *count_next) {
     // (tiles are looked at last-handed-out first: if the list overflows, the slow tiles left off it are
     // those the usual order starts early anyway)
     const unsigned n = (unsigned)(a.blocks_x * a.blocks_y);
@@ -103,7 +106,10 @@ __global__ __launch_bounds__(256) void split_plan_kernel(const RenderArgs a, uns
         const unsigned sample = (unsigned)(((unsigned long long)threadIdx.x * n) >> 8);
         atomicAdd(&sum16, min(tile_cost_of(a, sample), 1u << 20) >> 4);
         __syncthreads();
-        if (threadIdx.x == 0) count[1] = sum16 >> 4;  // (/ 256 tiles * 16)
+        if (threadIdx.x == 0) {
+            count[1] = sum16 >> 4;  // (/ 256 tiles * 16)
+            *count_next = 0;
+        }
     }
     // one atomic per wave that has a slow tile
     const unsigned long long slow_lanes = __builtin_amdgcn_ballot_w64(slow);
@@ -975,7 +981,9 @@ struct rm_engine {
     unsigned *d_tile_cost = nullptr;    // [frame tiles][4]
     unsigned *d_plan_words = nullptr;   // kPlanRing x (count padded to 64 words + list[kPlanCap])
     unsigned char *d_plan_flags = nullptr;  // kPlanRing x [frame tiles]
-    unsigned plan_next = 0;
+    hipStream_t plan_stream[8] = {};    // the stream each plan of the ring belongs to
+    bool plan_taken[8] = {};
+    unsigned char plan_parity[8] = {};  // which of a plan's two sets of count words its next launch uses
     int split_threshold = -1;           // ticks; 0 = off; -1 = not read yet (RM_SPLIT_US)
     bool split_on = true;               // rm_engine_set_tile_splitting
     unsigned split_times_mean = 3;      // ... and at least this many times the last launch's mean tile cost
@@ -1871,7 +1879,7 @@ int rm_engine_set_camera(rm_engine *e, const float position[3]) {
     return RM_OK;
 }
 
-constexpr unsigned kPlanRing = 8;      // plans of launches that may be in flight at once (streams, frames in flight)
+constexpr unsigned kPlanRing = 8;      // plans, one per stream that launches frames of this engine
 constexpr unsigned kPlanCap = 1024;    // tiles listed for quarters per launch at most
 constexpr unsigned kPlanCapEarly = 65536;  // ... listed to go first in a long launch
 constexpr unsigned kPlanStride = 64 + kPlanCapEarly;  // words per plan: the count in a line of its own, then the list
@@ -1910,8 +1918,25 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
             HIP_TRY(hipMemsetAsync(e->d_plan_words, 0, (size_t)kPlanRing * kPlanStride * sizeof(unsigned), e->stream));
             HIP_TRY(dev_alloc(&e->d_plan_flags, (size_t)kPlanRing * frame_tiles));
         }
-        const unsigned slot = e->plan_next++ % kPlanRing;
-        unsigned *count = e->d_plan_words + (size_t)slot * kPlanStride, *list = count + 64;
+        // A plan is written and read in the order of one stream, so each stream that launches frames has a
+        // plan of its own (launches on one stream cannot overlap); a ninth stream's launches go unplanned.
+        static_assert(kPlanRing == 8, "rm_engine::plan_stream holds one stream per plan of the ring");
+        unsigned slot = kPlanRing;
+        for (unsigned i = 0; i < kPlanRing && slot == kPlanRing; i++)
+            if (e->plan_taken[i] && e->plan_stream[i] == e->stream) slot = i;
+        for (unsigned i = 0; i < kPlanRing && slot == kPlanRing; i++)
+            if (!e->plan_taken[i]) {
+                e->plan_taken[i] = true;
+                e->plan_stream[i] = e->stream;
+                slot = i;
+            }
+        if (slot == kPlanRing) {
+            RM_LAUNCH(render_kernel, e, grid, dim3(BLOCK_THREADS), a);
+            return RM_OK;
+        }
+        unsigned *const words = e->d_plan_words + (size_t)slot * kPlanStride, *list = words + 64;
+        unsigned *count = words + 16 * e->plan_parity[slot], *count_next = words + 16 * (e->plan_parity[slot] ^ 1);
+        e->plan_parity[slot] ^= 1;
         unsigned char *flag = e->d_plan_flags + (size_t)slot * frame_tiles;
         a.tile_cost = e->d_tile_cost;
         a.cost_tiles = (unsigned)frame_tiles;
@@ -1921,10 +1946,10 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         a.plan_per = long_launch ? 1u : 4u;
 #endif
         a.plan_cap = std::min<unsigned>(long_launch ? kPlanCapEarly : kPlanCap, std::max<unsigned>(16u, grid.x / 16u));
-        const unsigned *previous = e->last_plan_count ? e->last_plan_count : count + 8;  // (the first plan: words that stay zero)
-        HIP_TRY(hipMemsetAsync(count, 0, sizeof(unsigned), e->stream));
+        const unsigned *previous = e->last_plan_count ? e->last_plan_count : words + 32;  // (the first plan: words that stay zero)
         hipLaunchKernelGGL(split_plan_kernel, dim3((grid.x + 255) / 256), dim3(256), 0, e->stream, a, count, list, flag,
-                           (unsigned)e->split_threshold, previous, long_launch ? e->early_times_mean : e->split_times_mean);
+                           (unsigned)e->split_threshold, previous, long_launch ? e->early_times_mean : e->split_times_mean,
+                           count_next);
         a.plan_count = count;
         e->last_plan_count = count;
         e->last_plan_cap = a.plan_cap;
