@@ -305,6 +305,42 @@ def test_slow_tiles_in_quarters_render_the_same_frame(scene, oracle_lightmaps, t
     planned.close()
 
 
+def test_planned_launches_on_many_streams(scene, oracle_lightmaps):
+    """Each stream that launches frames of an engine has a plan of its own (eight of them; further
+    streams' launches go unplanned): ten streams render the frame three times each, launches in
+    flight side by side, and every frame equals the one rendered with the plans switched off."""
+    import torch
+
+    from raymarching_amd import Engine
+
+    lm, _ = oracle_lightmaps
+    w, h = 1280, 720
+    e = Engine(scene, w, h)
+    for i, values in enumerate(lm[-1]):
+        e.set_lightmap(i, values)
+    e.set_tile_splitting(False)
+    main = torch.cuda.current_stream()
+    e.set_stream(main.cuda_stream)
+    want = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    e.render_rows_device(want.data_ptr(), 0, h)
+    e.synchronize()
+    e.set_tile_splitting(True)
+    streams = [torch.cuda.Stream() for _ in range(10)]
+    frames = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in streams]
+    torch.cuda.synchronize()
+    for turn in range(3):
+        for st, buf in zip(streams, frames):
+            e.set_stream(st.cuda_stream)
+            e.render_rows_device(buf.data_ptr(), 0, h)
+        torch.cuda.synchronize()
+        for k, buf in enumerate(frames):
+            assert torch.equal(buf, want), (turn, k)
+            buf.zero_()
+        torch.cuda.synchronize()
+    e.set_stream(main.cuda_stream)
+    e.close()
+
+
 def test_headless_host_harness(tmp_path, scene, oracle_lightmaps):
     """The C++ host mirror of main.rs (host/main.cpp) renders the default frame through the C ABI."""
     import os
