@@ -234,8 +234,8 @@ def test_probe_shade_outside_the_usual_ranges(scene, oracle_lightmaps, intensity
     ora.close()
 
 
-@pytest.mark.parametrize("threshold_us", [None, 5.0, 0.2])
-def test_slow_tiles_in_quarters_render_the_same_frame(scene, oracle_lightmaps, threshold_us, monkeypatch):
+@pytest.mark.parametrize("threshold_us,size", [(None, (1280, 720)), (5.0, (1280, 720)), (0.2, (1280, 720)), (5.0, (1001, 699))])
+def test_slow_tiles_in_quarters_render_the_same_frame(scene, oracle_lightmaps, threshold_us, size, monkeypatch):
     """Launches planned from the tiles' last timings (slow tiles first, as four waves of 4x4 pixels):
     every frame equals the one rendered with the plans switched off, for whole frames, row ranges that
     do not start on a tile boundary, strips, and a camera that has moved since the timings were taken.
@@ -248,7 +248,7 @@ def test_slow_tiles_in_quarters_render_the_same_frame(scene, oracle_lightmaps, t
         monkeypatch.setenv("RM_SPLIT_US", str(threshold_us))
         monkeypatch.setenv("RM_SPLIT_TIMES_MEAN", "0")  # the absolute threshold alone decides
     lm, _ = oracle_lightmaps
-    w, h = 1280, 720
+    w, h = size  # (the second size ends in partial tiles on both axes)
 
     def engine(split):
         e = Engine(scene, w, h)
@@ -284,15 +284,14 @@ def test_slow_tiles_in_quarters_render_the_same_frame(scene, oracle_lightmaps, t
             if first_pose_frame is None:
                 first_pose_frame = got.cpu().numpy()
         assert torch.equal(rows(planned, 100, 613), want[100:613])
-        got = strips(planned, 1, 3, 30)
-        for k in range(30):
-            r = (1 + 3 * k) * 8
-            assert torch.equal(got[k * 8:(k + 1) * 8], want[r:r + 8]), (pose, k)
-        got = strips(planned, 2, 4, 23)  # the last strip named (90) lies below the frame's 90 strips
-        for k in range(22):
-            r = (2 + 4 * k) * 8
-            assert torch.equal(got[k * 8:(k + 1) * 8], want[r:r + 8]), (pose, k)
-        assert int(got[22 * 8:].max()) == 0
+        for first, stride, n in ((1, 3, 30), (2, 4, 23)):  # (the last strips named lie below the frame)
+            got = strips(planned, first, stride, n)
+            for k in range(n):
+                r = (first + stride * k) * 8
+                inside = max(0, min(8, h - r))
+                assert torch.equal(got[k * 8:k * 8 + inside], want[r:r + inside]), (pose, first, k)
+                below = got[k * 8 + inside:(k + 1) * 8]
+                assert below.numel() == 0 or int(below.max()) == 0
     print(f"threshold {threshold_us}: tiles in quarters per whole-frame launch {split_counts}")
     assert split_counts[0] == 0  # nothing is known before the first frame
     assert max(split_counts) > 0
