@@ -285,14 +285,16 @@ int rm_engine_set_march_cap(rm_engine *engine, int max_steps);
  * launch of fewer than 65536 tiles lasts as long as its slowest wave, so the frame kernel renders
  * the tiles that took longest the last time they were rendered first and as four waves of 4x4
  * pixels each (a quarter's pixels drift apart less between reflection levels: 0.6 of the time).
- * A longer launch of a scene with a spatial index only hands its slow tiles out first, whole.
- * A tile counts as slow at 45 us for a quarter and at least three times the mean tile of the
- * engine's previous planned launch (RM_SPLIT_US and RM_SPLIT_TIMES_MEAN in the environment set the
- * two, RM_SPLIT_US=0 switches the plans off).  On by default.  A caller that keeps several launches of one engine in flight, where the
- * machine is busy anyway and the quarters' idle lanes cost throughput, switches it off
- * (rm_group_create does for more than one frame in flight, unless a rank's share is below 20000
- * tiles, where the plans still pay).  rm_engine_split_tiles waits for the
- * engine's work and reports how many tiles the most recent planned launch rendered in quarters. */
+ * A tile counts as slow there at 45 us for a quarter and at least three times the mean tile of
+ * the engine's previous planned launch (RM_SPLIT_US and RM_SPLIT_TIMES_MEAN in the environment set
+ * the two; RM_SPLIT_US=0 switches every plan off).  A longer launch of a scene with a spatial index
+ * only hands out first, whole, the tiles that took at least twice the mean (RM_EARLY_TIMES_MEAN).
+ * Each stream that launches frames of an engine has a plan of its own, up to eight streams; the
+ * launches of further streams go unplanned.  On by default.  A caller that keeps several launches of
+ * one engine in flight, where the machine is busy anyway and the quarters' idle lanes cost
+ * throughput, switches it off (rm_group_create does for more than one frame in flight, unless a
+ * rank's share is below 20000 tiles, where the plans still pay).  rm_engine_split_tiles waits for
+ * the engine's work and reports how many tiles the most recent planned launch had on its list. */
 int rm_engine_set_tile_splitting(rm_engine *engine, int on);
 int rm_engine_split_tiles(rm_engine *engine, uint32_t *count);
 
