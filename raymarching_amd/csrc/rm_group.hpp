@@ -183,6 +183,7 @@ static rm_group *group_build(rm_engine *e, int rank, int world, int frames_in_fl
     // 32400 tiles - are 10 % slower with the plans, an eighth - 16200 tiles - 6-23 % faster).
     const long share_tiles = (long)g->strips_per_rank * ((e->W + TILE - 1) / TILE);
     if (frames_in_flight > 1 && share_tiles > 20000) e->split_on = false;
+    if (frames_in_flight > 1 && !getenv("RM_DENSE_TILES")) e->dense_tiles = frames_in_flight >= 3 ? kOverlapDenseTiles3 : kOverlapDenseTiles2;
     g->band_pixels = (size_t)g->strips_per_rank * RM_STRIP_ROWS * e->W;
     g->packed = e->W % 4 == 0 && e->H <= 65535;
     const size_t wire = g->packed ? 3 : 4;

@@ -324,6 +324,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, MinWavesDense<G>::value) void render
     render_tile<G, false>(a, g);
 }
 constexpr unsigned kDenseLaunchTiles = 65536;  // between 1920x1080 (32400 tiles) and 3840x2160 (129600)
+// ... and where a group keeps three or more (two) frames in flight: the machine then stays full across
+// launches, and the 8-wave build pays for smaller ones (shares of the 3840x2160 frame, 8-wave build
+// against the 7-wave one: a half 0.129/0.128 against 0.135/0.135 ms with two/three in flight, a quarter
+// 0.077/0.065 against 0.072/0.067 ms)
+constexpr unsigned kOverlapDenseTiles3 = 20000, kOverlapDenseTiles2 = 50000;
 
 // ---- the frame in two passes (an experiment: RM_TWO_PASS=1) -------------------------------------
 //
@@ -986,6 +991,7 @@ struct rm_engine {
     unsigned char plan_parity[8] = {};  // which of a plan's two sets of count words its next launch uses
     int split_threshold = -1;           // ticks; 0 = off; -1 = not read yet (RM_SPLIT_US)
     bool split_on = true;               // rm_engine_set_tile_splitting
+    unsigned dense_tiles = 0;           // launches of the small tiers from this many tiles on take the 8-wave build (0 = the default)
     unsigned split_times_mean = 3;      // ... and at least this many times the last launch's mean tile cost
     unsigned early_times_mean = 2;      // the same for the tiles a long launch hands out first (RM_EARLY_TIMES_MEAN)
     const unsigned *last_plan_count = nullptr;  // the count word of the most recent plan (device)
@@ -1886,7 +1892,11 @@ constexpr unsigned kPlanStride = 64 + kPlanCapEarly;  // words per plan: the cou
 
 static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
     const bool long_launch = grid.x >= kDenseLaunchTiles;
-    if (e->tier <= 1 && long_launch) {
+    if (e->dense_tiles == 0) {
+        const char *v = getenv("RM_DENSE_TILES");  // (for measurements)
+        e->dense_tiles = v && atoi(v) > 0 ? (unsigned)atoi(v) : kDenseLaunchTiles;
+    }
+    if (e->tier <= 1 && grid.x >= e->dense_tiles) {
         // the small tiers (scene in scalar registers) have the 8-wave build for this, and no tail worth a
         // plan: the 3840x2160 frame takes 0.284 ms with its slow tiles first against 0.283 ms without
         RM_LAUNCH(render_dense_kernel, e, grid, dim3(BLOCK_THREADS), a0);
