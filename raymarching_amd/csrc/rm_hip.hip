@@ -1904,7 +1904,8 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
     }
     RenderArgs a = a0;
 #if !defined(RM_DIAG)
-    // A launch that long launches hide nothing of: its slow tiles go first and in quarters (SplitPlan).
+    // Every other launch is planned from the tiles' last lifetimes (see RenderArgs): a short one renders
+    // its slow tiles first and in quarters, a long one (a large scene) only hands them out first.
     if (e->split_threshold < 0) {
         const char *v = getenv("RM_SPLIT_US");  // threshold for a quarter in microseconds; 0 switches the plans off
         const double us = v ? atof(v) : kSplitThresholdTicks / 100.0;
@@ -1915,11 +1916,11 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         if (m2) e->early_times_mean = (unsigned)std::min(std::max(atoi(m2), 0), 1000);
     }
     const size_t frame_tiles = (size_t)((e->W + TILE - 1) / TILE) * ((e->H + TILE - 1) / TILE + 1);
-    // (a launch that names more tiles than the frame has - strips far below it - is not planned: the
-    // plan's flags are one per frame tile)
     // A long launch of a large scene keeps the machine full but ends with the slow tiles of the rows
     // handed out last (the 7680x4320 stress frame: 99 % of the waves have ended after 14.2 of 15.8 ms):
     // its plan lists the slow tiles to go first, whole - quarters would cost throughput there.
+    // (A launch that names more tiles than the frame has - strips far below it - is not planned: the
+    // plan's flags are one per frame tile.)
     if (e->split_on && e->split_threshold > 0 && grid.x <= frame_tiles) {
         if (!e->d_tile_cost) {
             HIP_TRY(dev_alloc(&e->d_tile_cost, frame_tiles * 4));
