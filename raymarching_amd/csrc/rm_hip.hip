@@ -270,6 +270,17 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, const G &g) {
 #endif
     }
 #endif
+    if constexpr (!PLANS) {
+        // The pixel's place in the frame, worked out again from the lane and workgroup numbers (through a
+        // copy of the lane number the compiler cannot trace back): kept from the top of the kernel, the
+        // three values would each cost the 64-register build a spill - 1 KiB written per wave.
+        int lane_again = (int)threadIdx.x;
+        asm volatile("" : "+v"(lane_again));
+        lane_again &= 63;
+        const int by = a.blocks_y - 1 - (int)(blockIdx.x / (unsigned)a.blocks_x), bx = (int)(blockIdx.x % (unsigned)a.blocks_x);
+        x = bx * TILE + (lane_again & 7);
+        out_row = by * TILE + (lane_again >> 3);
+    }
     *reinterpret_cast<unsigned *>(a.out + (size_t)out_row * a.pitch + (size_t)x * 4) = px;
 #if !defined(RM_DIAG)
     if (PLANS && a.tile_cost && (threadIdx.x & 63) == 0) {
