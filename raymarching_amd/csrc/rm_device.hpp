@@ -270,6 +270,14 @@ struct SceneSmallAcc {
         for (int i = 0; i < G::kPlanes; i++)
             if (G::kExact || i < g.n_gp) f(g.idx_gp[i], g.gp[i][0], g.gp[i][1], g.gp[i][2], g.gp[i][3]);
     }
+    // the four groups of planes in the order of the fold
+    template <class FX, class FY, class FZ, class FP>
+    RM_DEV void all_planes(FX &&fx, FY &&fy, FZ &&fz, FP &&fp) const {
+        axis<0>(fx);
+        axis<1>(fy);
+        axis<2>(fz);
+        planes(fp);
+    }
     template <class F>
     RM_DEV void boxes(F &&) const {}  // scenes with boxes or smooth unions use the large layout
     static constexpr bool kSmooth = false;
@@ -312,6 +320,25 @@ struct SceneLargeAcc {
         ConstInts idx = constant(g.idx_gp);
         ConstFloats gp = constant(g.gp);
         for (int i = 0; i < g.n_gp; i++) f(idx[i], gp[4 * i], gp[4 * i + 1], gp[4 * i + 2], gp[4 * i + 3]);
+    }
+    // the same four groups out of the one array of records (a scalar load and a scalar branch per plane)
+    template <class FX, class FY, class FZ, class FP>
+    RM_DEV void all_planes(FX &&fx, FY &&fy, FZ &&fz, FP &&fp) const {
+        typedef float Float8 __attribute__((ext_vector_type(8)));
+        typedef const __attribute__((address_space(4))) Float8 *ConstFloat8s;
+        const ConstFloat8s rec = (ConstFloat8s)g.planes_all;
+        for (int i = 0; i < g.n_planes_all; i++) {
+            const Float8 r = rec[i];
+            const int kind = __float_as_int(r[0]), oi = __float_as_int(r[1]);
+            if (kind == 0)
+                fx(oi, r[2], r[3]);
+            else if (kind == 1)
+                fy(oi, r[2], r[3]);
+            else if (kind == 2)
+                fz(oi, r[2], r[3]);
+            else
+                fp(oi, r[2], r[3], r[4], r[5]);
+        }
     }
     template <class F>
     RM_DEV void boxes(F &&f) const {
@@ -408,51 +435,59 @@ RM_DEV float box_sdf(V3 c, V3 h, V3 p) {
 // Spatial index lookup for a point: the list ranges of its cell, empty for a point outside the
 // grid (or a NaN).
 struct CellLists {
-    int s0, s1, b0, b1;
-    float reach;  // every primitive outside the lists is at least this far from p
+    int s_at, ns, b_at, nb;  // where the blocks start in the pool, and their entry counts
+    float reach;             // every primitive outside the lists is at least this far from p
 };
-RM_DEV CellLists grid_cell(const GridView &gv, const GridLevel &lv, V3 p) {
+RM_DEV CellLists grid_cell(const GridView &gv, int level, V3 p) {
     const float fx = (p.x - gv.ox) * gv.inv_cell, fy = (p.y - gv.oy) * gv.inv_cell, fz = (p.z - gv.oz) * gv.inv_cell;
     const bool inside = fx >= 0.0f && fx < (float)gv.nx && fy >= 0.0f && fy < (float)gv.ny && fz >= 0.0f && fz < (float)gv.nz;
     CellLists c = {0, 0, 0, 0, gv.reach};
     const int cell = inside ? ((int)fz * gv.ny + (int)fy) * gv.nx + (int)fx : -1;  // non-negative: truncation is floor
     const int ucell = __builtin_amdgcn_readfirstlane(cell);
+    const ConstInt4s table = (ConstInt4s)gv.pool + (size_t)level * gv.cells;
     if (ucell >= 0 && wave_all(cell == ucell)) {
         // every lane in the same cell (the usual case for a tile): its record comes by a scalar load
-        const Int4 rec = ((ConstInt4s)lv.cell)[ucell];
-        c.s0 = rec.x;
-        c.s1 = rec.x + (rec.z & 0xffff);
-        c.b0 = rec.y;
-        c.b1 = rec.y + ((unsigned)rec.z >> 16);
+        const Int4 rec = table[ucell];
+        c.s_at = rec.x;
+        c.ns = rec.z & 0xffff;
+        c.b_at = rec.y;
+        c.nb = (unsigned)rec.z >> 16;
         c.reach = __int_as_float(rec.w);
         return c;
     }
     if (inside) {
-        const Int4 rec = ((ConstInt4s)lv.cell)[cell];  // one 16-byte record: first sphere, first box, counts, reach
-        c.s0 = rec.x;
-        c.s1 = rec.x + (rec.z & 0xffff);
-        c.b0 = rec.y;
-        c.b1 = rec.y + ((unsigned)rec.z >> 16);
+        const Int4 rec = table[cell];
+        c.s_at = rec.x;
+        c.ns = rec.z & 0xffff;
+        c.b_at = rec.y;
+        c.nb = (unsigned)rec.z >> 16;
         c.reach = __int_as_float(rec.w);
     }
     return c;
 }
+// One sphere (box) of a block, fetched by a lane of its own.
+struct SphereEntry {
+    Float4 g;
+    int oi;
+};
+RM_DEV SphereEntry grid_sphere(const GridView &gv, int s_at, int j) {
+    const ConstInts group = constant(gv.pool) + s_at + kGridSphereGroup * (j >> 2);
+    SphereEntry e;
+    e.g = *(ConstFloat4s)(group + 4 * (j & 3));
+    e.oi = group[16 + (j & 3)];
+    return e;
+}
+struct BoxEntry {
+    Float4 g0, g1;  // cx, cy, cz, hx | hy, hz, object index, -
+};
+RM_DEV BoxEntry grid_box(const GridView &gv, int b_at, int j) {
+    const ConstFloat4s rec = (ConstFloat4s)(constant(gv.pool) + b_at + 8 * j);
+    BoxEntry e;
+    e.g0 = rec[0];
+    e.g1 = rec[1];
+    return e;
+}
 
-// The sphere and box part of the fold below, done over the lists of p's grid cell only.  Returns
-// whether the value is certain to equal the fold over every sphere and box; `r` enters as the value
-// after the planes and leaves as the result.
-//
-// Every primitive missing from the lists is at least R = reach away.
-//   * Hard minimum: if the minimum over planes and listed primitives is <= R, no missing one can
-//     lower it.
-//   * Smooth minimum, folded in order: a missing primitive is a no-op whenever the running value is
-//     <= R - k at its turn, and the running value never rises.  That holds from the start if the
-//     planes already bring it there.  Otherwise the fold over the listed primitives may differ from
-//     the full one until a listed primitive with distance s arrives that lies 2k below everything
-//     folded before it (planes, listed ones, and R for the missing ones): a running value is never
-//     more than k below the minimum of what was folded, so at that turn the gap is >= k in both
-//     folds, both take exactly s (<= R - 2k), and from there on they agree.  (`slack` keeps the
-//     comparison clear of the rounding of the two sums.)
 // The state of one fold over a cell's lists, kept in plain values (not captured by reference in
 // closures: the compiler then keeps it in registers instead of private memory).
 struct FoldState {
@@ -525,9 +560,9 @@ typedef const __attribute__((address_space(4))) Int4u *ConstInt4us;
 //     folds, both take exactly s (<= R - 2k), and from there on they agree.  (`slack` keeps the
 //     comparison clear of the rounding of the two sums.)
 template <class SC, class IGN>
-RM_DEV bool grid_fold(const SC &sc, const GridLevel &lv, V3 p, const IGN &ign, float &r_io, float k, bool blend) {
+RM_DEV bool grid_fold(const SC &sc, int level, V3 p, const IGN &ign, float &r_io, float k, bool blend) {
     const GridView &gv = sc.grid();
-    const CellLists c = grid_cell(gv, lv, p);
+    const CellLists c = grid_cell(gv, level, p);
     const float R = c.reach;
     const float slack = 2.01f * k + 1e-4f;
     FoldState st;
@@ -535,28 +570,27 @@ RM_DEV bool grid_fold(const SC &sc, const GridLevel &lv, V3 p, const IGN &ign, f
     st.reach = blend ? r_io + k : r_io;
     st.certain = r_io <= R - k;  // blend only
     st.floor_before = rs_min(r_io, R);
-    const ConstFloat4s sph_geom = (ConstFloat4s)lv.sph_geom, box_geom = (ConstFloat4s)lv.box_geom;
-    const ConstInts sph_index = constant(lv.sph_index), box_index = constant(lv.box_index);
     // The pixels of a tile mostly sit in one cell.  A wave whose lanes all do walks the lists with
     // wave-uniform indices: the entries arrive by scalar loads, once per wave, and no lane waits for
     // another's longer list.  Four spheres (two boxes) come with one 64-byte load, so that the wave
-    // waits for memory once per group and not once per entry (the arrays are padded by one group).
-    const int us0 = __builtin_amdgcn_readfirstlane(c.s0), us1 = __builtin_amdgcn_readfirstlane(c.s1);
-    const int ub0 = __builtin_amdgcn_readfirstlane(c.b0), ub1 = __builtin_amdgcn_readfirstlane(c.b1);
-    if (wave_all(c.s0 == us0 && c.s1 == us1 && c.b0 == ub0 && c.b1 == ub1)) {
-        for (int e = us0; e < us1; e += 4) {
-            const Float16 g = *(ConstFloat16s)(constant(lv.sph_geom) + 4 * e);
-            const Int4 oi = *(ConstInt4us)(sph_index + e);
+    // waits for memory once per group and not once per entry.
+    const int us_at = __builtin_amdgcn_readfirstlane(c.s_at), uns = __builtin_amdgcn_readfirstlane(c.ns);
+    const int ub_at = __builtin_amdgcn_readfirstlane(c.b_at), unb = __builtin_amdgcn_readfirstlane(c.nb);
+    if (wave_all(c.s_at == us_at && c.ns == uns && c.b_at == ub_at && c.nb == unb)) {
+        ConstInts group = constant(gv.pool) + us_at;
+        for (int e = 0; e < uns; e += 4, group += kGridSphereGroup) {
+            const Float16 g = *(ConstFloat16s)group;
+            const Int4 oi = *(ConstInt4us)(group + 16);
             st = fold_sphere(st, ign, p, g.s0, g.s1, g.s2, g.s3, oi.x, k, slack, blend);
-            if (e + 1 < us1) st = fold_sphere(st, ign, p, g.s4, g.s5, g.s6, g.s7, oi.y, k, slack, blend);
-            if (e + 2 < us1) st = fold_sphere(st, ign, p, g.s8, g.s9, g.sa, g.sb, oi.z, k, slack, blend);
-            if (e + 3 < us1) st = fold_sphere(st, ign, p, g.sc, g.sd, g.se, g.sf, oi.w, k, slack, blend);
+            if (e + 1 < uns) st = fold_sphere(st, ign, p, g.s4, g.s5, g.s6, g.s7, oi.y, k, slack, blend);
+            if (e + 2 < uns) st = fold_sphere(st, ign, p, g.s8, g.s9, g.sa, g.sb, oi.z, k, slack, blend);
+            if (e + 3 < uns) st = fold_sphere(st, ign, p, g.sc, g.sd, g.se, g.sf, oi.w, k, slack, blend);
         }
-        for (int e = ub0; e < ub1; e += 2) {
-            const Float16 g = *(ConstFloat16s)(constant(lv.box_geom) + 8 * e);
-            const int o0 = box_index[e], o1 = box_index[e + 1];
-            st = fold_box(st, ign, p, v3(g.s0, g.s1, g.s2), v3(g.s3, g.s4, g.s5), o0, k, slack, blend);
-            if (e + 1 < ub1) st = fold_box(st, ign, p, v3(g.s8, g.s9, g.sa), v3(g.sb, g.sc, g.sd), o1, k, slack, blend);
+        ConstInts pair = constant(gv.pool) + ub_at;
+        for (int e = 0; e < unb; e += 2, pair += 16) {
+            const Float16 g = *(ConstFloat16s)pair;
+            st = fold_box(st, ign, p, v3(g.s0, g.s1, g.s2), v3(g.s3, g.s4, g.s5), __float_as_int(g.s6), k, slack, blend);
+            if (e + 1 < unb) st = fold_box(st, ign, p, v3(g.s8, g.s9, g.sa), v3(g.sb, g.sc, g.sd), __float_as_int(g.se), k, slack, blend);
         }
         r_io = st.r;
         return blend ? st.certain : (st.r <= R);
@@ -564,32 +598,23 @@ RM_DEV bool grid_fold(const SC &sc, const GridLevel &lv, V3 p, const IGN &ign, f
     // Otherwise every lane walks its own lists.  Entries are fetched four (boxes: two) at a time
     // before any is used, so that a list costs one memory round trip per group instead of one per
     // entry; they are folded one by one, in order.
-    for (int e = c.s0; e < c.s1; e += 4) {
-        Float4 g[4];
-        int oi[4];
+    for (int e = 0; e < c.ns; e += 4) {
+        SphereEntry s[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int ee = min(e + u, c.s1 - 1);
-            g[u] = sph_geom[ee];
-            oi[u] = sph_index[ee];
-        }
+        for (int u = 0; u < 4; u++) s[u] = grid_sphere(gv, c.s_at, min(e + u, c.ns - 1));
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (e + u < c.s1) st = fold_sphere(st, ign, p, g[u].x, g[u].y, g[u].z, g[u].w, oi[u], k, slack, blend);
+            if (e + u < c.ns) st = fold_sphere(st, ign, p, s[u].g.x, s[u].g.y, s[u].g.z, s[u].g.w, s[u].oi, k, slack, blend);
     }
-    for (int e = c.b0; e < c.b1; e += 2) {
-        Float4 g0[2], g1[2];
-        int oi[2];
+    for (int e = 0; e < c.nb; e += 2) {
+        BoxEntry b[2];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int ee = min(e + u, c.b1 - 1);
-            g0[u] = box_geom[2 * ee];
-            g1[u] = box_geom[2 * ee + 1];
-            oi[u] = box_index[ee];
-        }
+        for (int u = 0; u < 2; u++) b[u] = grid_box(gv, c.b_at, min(e + u, c.nb - 1));
 #pragma unroll
         for (int u = 0; u < 2; u++)
-            if (e + u < c.b1) st = fold_box(st, ign, p, v3(g0[u].x, g0[u].y, g0[u].z), v3(g0[u].w, g1[u].x, g1[u].y), oi[u], k, slack, blend);
+            if (e + u < c.nb)
+                st = fold_box(st, ign, p, v3(b[u].g0.x, b[u].g0.y, b[u].g0.z), v3(b[u].g0.w, b[u].g1.x, b[u].g1.y), __float_as_int(b[u].g1.z), k, slack,
+                              blend);
     }
     r_io = st.r;
     return blend ? st.certain : (st.r <= R);
@@ -623,18 +648,19 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, LaneMask act, SphereB
         else
             return dir * (pc - off);
     };
-    sc.template axis<0>([&](int oi, float off, float dir) {
-        if (!ign.skip(oi)) fold(ign.mask(oi, axis_sdf(p.x, off, dir)));
-    });
-    sc.template axis<1>([&](int oi, float off, float dir) {
-        if (!ign.skip(oi)) fold(ign.mask(oi, axis_sdf(p.y, off, dir)));
-    });
-    sc.template axis<2>([&](int oi, float off, float dir) {
-        if (!ign.skip(oi)) fold(ign.mask(oi, axis_sdf(p.z, off, dir)));
-    });
-    sc.planes([&](int oi, float nx, float ny, float nz, float dist) {
-        if (!ign.skip(oi)) fold(ign.mask(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist));
-    });
+    sc.all_planes(
+        [&](int oi, float off, float dir) {
+            if (!ign.skip(oi)) fold(ign.mask(oi, axis_sdf(p.x, off, dir)));
+        },
+        [&](int oi, float off, float dir) {
+            if (!ign.skip(oi)) fold(ign.mask(oi, axis_sdf(p.y, off, dir)));
+        },
+        [&](int oi, float off, float dir) {
+            if (!ign.skip(oi)) fold(ign.mask(oi, axis_sdf(p.z, off, dir)));
+        },
+        [&](int oi, float nx, float ny, float nz, float dist) {
+            if (!ign.skip(oi)) fold(ign.mask(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist));
+        });
     if constexpr (SC::kGrid) {
         if (sc.grid().cells > 0) {
             if (!active) return d;
@@ -646,7 +672,7 @@ RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, LaneMask act, SphereB
             for (int level = 0; level < kGridLevels; level++) {
                 float r = d;
                 if (level > 0) diag_event(0);  // the short lists left the value open
-                if (grid_fold(sc, sc.grid().level[level], p, ign, r, k, blend)) return r;
+                if (grid_fold(sc, level, p, ign, r, k, blend)) return r;
             }
             diag_event(7);
         }
@@ -701,41 +727,39 @@ RM_DEV int closest_index(const SC &sc, V3 p, float, const IGN &ign, bool spheres
         best = better ? s : best;
         bi = better ? oi : bi;
     };
-    sc.template axis<0>([&](int oi, float off, float dir) {
-        if (!ign.skip(oi)) take(oi, dir * (p.x - off));
-    });
-    sc.template axis<1>([&](int oi, float off, float dir) {
-        if (!ign.skip(oi)) take(oi, dir * (p.y - off));
-    });
-    sc.template axis<2>([&](int oi, float off, float dir) {
-        if (!ign.skip(oi)) take(oi, dir * (p.z - off));
-    });
-    sc.planes([&](int oi, float nx, float ny, float nz, float dist) {
-        if (!ign.skip(oi)) take(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist);
-    });
+    sc.all_planes(
+        [&](int oi, float off, float dir) {
+            if (!ign.skip(oi)) take(oi, dir * (p.x - off));
+        },
+        [&](int oi, float off, float dir) {
+            if (!ign.skip(oi)) take(oi, dir * (p.y - off));
+        },
+        [&](int oi, float off, float dir) {
+            if (!ign.skip(oi)) take(oi, dir * (p.z - off));
+        },
+        [&](int oi, float nx, float ny, float nz, float dist) {
+            if (!ign.skip(oi)) take(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist);
+        });
     if constexpr (SC::kGrid) {
         if (sc.grid().cells > 0) {
             // the primitives missing from a cell's lists are at least its reach away: a best
             // distance below that cannot be theirs (re-taking a primitive changes nothing)
             const GridView &gv = sc.grid();
-            auto take_lists = [&](const GridLevel &lv) {
-                const CellLists c = grid_cell(gv, lv, p);
-                const ConstFloat4s sph_geom = (ConstFloat4s)lv.sph_geom, box_geom = (ConstFloat4s)lv.box_geom;
-                const ConstInts sph_index = constant(lv.sph_index), box_index = constant(lv.box_index);
-                for (int e = c.s0; e < c.s1; e++) {
-                    const Float4 g = sph_geom[e];
-                    const int oi = sph_index[e];
-                    if (!ign.skip(oi)) take(oi, sqrt_rn(mag_sqd(p - v3(g.x, g.y, g.z))) - g.w);
+            auto take_lists = [&](int level) {
+                const CellLists c = grid_cell(gv, level, p);
+                for (int e = 0; e < c.ns; e++) {
+                    const SphereEntry s = grid_sphere(gv, c.s_at, e);
+                    if (!ign.skip(s.oi)) take(s.oi, sqrt_rn(mag_sqd(p - v3(s.g.x, s.g.y, s.g.z))) - s.g.w);
                 }
-                for (int e = c.b0; e < c.b1; e++) {
-                    const Float4 g0 = box_geom[2 * e], g1 = box_geom[2 * e + 1];
-                    const int oi = box_index[e];
-                    if (!ign.skip(oi)) take(oi, box_sdf(v3(g0.x, g0.y, g0.z), v3(g0.w, g1.x, g1.y), p));
+                for (int e = 0; e < c.nb; e++) {
+                    const BoxEntry b = grid_box(gv, c.b_at, e);
+                    const int oi = __float_as_int(b.g1.z);
+                    if (!ign.skip(oi)) take(oi, box_sdf(v3(b.g0.x, b.g0.y, b.g0.z), v3(b.g0.w, b.g1.x, b.g1.y), p));
                 }
                 return c.reach;
             };
-            if (best < take_lists(gv.level[0])) return bi;
-            if (best < take_lists(gv.level[1])) return bi;
+            if (best < take_lists(0)) return bi;
+            if (best < take_lists(1)) return bi;
         }
     }
     if (!(spheres_out && !SC::kGrid))  // (with a spatial index the bound is not kept up on every step)

@@ -1273,6 +1273,27 @@ static int engine_upload(rm_engine *e) {
         HIP_TRY(up_f(g_gp, &gl.gp));
         HIP_TRY(up_i(gi_box, &gl.idx_box));
         HIP_TRY(up_f(g_box, &gl.box));
+        {
+            // the planes once more as one array of records in the order of the fold
+            std::vector<float> all;
+            auto word = [](int v) {
+                float f;
+                memcpy(&f, &v, sizeof f);
+                return f;
+            };
+            for (int a = 0; a < 3; a++)
+                for (size_t k = 0; k < gi_ax[a].size(); k++) {
+                    const float r[8] = {word(a), word(gi_ax[a][k]), g_ax[a][2 * k], g_ax[a][2 * k + 1], 0, 0, 0, 0};
+                    all.insert(all.end(), r, r + 8);
+                }
+            for (size_t k = 0; k < gi_gp.size(); k++) {
+                const float r[8] = {word(3),         word(gi_gp[k]),  g_gp[4 * k], g_gp[4 * k + 1],
+                                    g_gp[4 * k + 2], g_gp[4 * k + 3], 0,           0};
+                all.insert(all.end(), r, r + 8);
+            }
+            gl.n_planes_all = (int)(all.size() / 8);
+            HIP_TRY(up_f(all, &gl.planes_all));
+        }
 
         // Spatial index (see GridView) once the bounded primitives are many enough to pay for it.
         const int n_bounded = (int)gi_sph.size() + n_boxes;
@@ -1346,14 +1367,9 @@ static int engine_upload(rm_engine *e) {
                     int min_list, max_list;
                 } plans[kGridLevels] = {{0.0f, short_list, short_list}, {reach, min_list, max_list}};
                 struct LevelData {
-                    std::vector<int> s_start, b_start, s_index, b_index;
-                    std::vector<float> s_geom, b_geom, cell_reach;
+                    std::vector<float> cell_reach;
                 } lv[kGridLevels];
-                for (auto &l : lv) {
-                    l.s_start.assign(gv.cells + 1, 0);
-                    l.b_start.assign(gv.cells + 1, 0);
-                    l.cell_reach.assign(gv.cells, 0.0f);
-                }
+                for (auto &l : lv) l.cell_reach.assign(gv.cells, 0.0f);
                 const float origin[3] = {gv.ox, gv.oy, gv.oz};
                 // phase 1, host threads over slabs of cells: every cell's reach and member list per level
                 std::vector<std::vector<uint16_t>> members[kGridLevels];
@@ -1412,51 +1428,55 @@ static int engine_upload(rm_engine *e) {
                         pool.emplace_back(slab, (int)((long long)gv.nz * t / n_threads), (int)((long long)gv.nz * (t + 1) / n_threads));
                     for (auto &th : pool) th.join();
                 }
-                // phase 2: the lists one after the other, geometry in place
-                for (int L = 0; L < kGridLevels; L++)
-                    for (int c = 0; c < gv.cells; c++) {
-                        for (uint16_t i : members[L][c]) {
-                            if (i < gi_sph.size()) {
-                                lv[L].s_index.push_back(gi_sph[i]);
-                                lv[L].s_geom.insert(lv[L].s_geom.end(), &g_sph[4 * i], &g_sph[4 * i] + 4);
-                            } else {
-                                const int b = i - (int)gi_sph.size();
-                                lv[L].b_index.push_back(gi_box[b]);
-                                lv[L].b_geom.insert(lv[L].b_geom.end(), &g_box[8 * b], &g_box[8 * b] + 8);
-                            }
-                        }
-                        lv[L].s_start[c + 1] = (int)lv[L].s_index.size();
-                        lv[L].b_start[c + 1] = (int)lv[L].b_index.size();
-                    }
+                // phase 2: the pool (see GridView): both cell tables, then every cell's blocks
+                std::vector<int> pool(4 * (size_t)gv.cells * kGridLevels, 0);
+                const auto word = [](float f) {
+                    int v;
+                    memcpy(&v, &f, sizeof v);
+                    return v;
+                };
                 e->grid_entries = 0;
                 for (int L = 0; L < kGridLevels; L++) {
-                    std::vector<int> cell_rec(4 * (size_t)gv.cells);
+                    size_t entries = 0;
+                    int longest_list = 0;
                     for (int c = 0; c < gv.cells; c++) {
-                        cell_rec[4 * c] = lv[L].s_start[c];
-                        cell_rec[4 * c + 1] = lv[L].b_start[c];
-                        cell_rec[4 * c + 2] = (lv[L].s_start[c + 1] - lv[L].s_start[c]) | ((lv[L].b_start[c + 1] - lv[L].b_start[c]) << 16);
-                        memcpy(&cell_rec[4 * c + 3], &lv[L].cell_reach[c], sizeof(float));
+                        std::vector<int> sph, box;
+                        for (uint16_t i : members[L][c]) (i < gi_sph.size() ? sph : box).push_back(i);
+                        const size_t s_at = pool.size();
+                        for (size_t g0 = 0; g0 < sph.size(); g0 += 4) {
+                            int group[kGridSphereGroup];
+                            for (int u = 0; u < 4; u++) {
+                                const bool there = g0 + u < sph.size();
+                                for (int w = 0; w < 4; w++) group[4 * u + w] = there ? word(g_sph[4 * sph[g0 + u] + w]) : 0;
+                                group[16 + u] = there ? gi_sph[sph[g0 + u]] : -1;
+                            }
+                            pool.insert(pool.end(), group, group + kGridSphereGroup);
+                        }
+                        const size_t b_at = pool.size();
+                        for (int i : box) {
+                            const int b = i - (int)gi_sph.size();
+                            int rec[8];
+                            for (int w = 0; w < 6; w++) rec[w] = word(g_box[8 * b + w]);
+                            rec[6] = gi_box[b];
+                            rec[7] = 0;
+                            pool.insert(pool.end(), rec, rec + 8);
+                        }
+                        int *rec = &pool[4 * ((size_t)L * gv.cells + c)];
+                        rec[0] = (int)s_at;
+                        rec[1] = (int)b_at;
+                        rec[2] = (int)sph.size() | ((int)box.size() << 16);
+                        rec[3] = word(lv[L].cell_reach[c]);
+                        entries += sph.size() + box.size();
+                        longest_list = std::max(longest_list, (int)(sph.size() + box.size()));
                     }
-                    e->grid_entries += lv[L].s_index.size() + lv[L].b_index.size();
-                    // the kernels fetch a wave-uniform list four spheres (two boxes) at a time: one group of padding
-                    lv[L].s_geom.resize(lv[L].s_geom.size() + 4 * 4, 0.0f);
-                    lv[L].s_index.resize(lv[L].s_index.size() + 4, -1);
-                    lv[L].b_geom.resize(lv[L].b_geom.size() + 2 * 8, 0.0f);
-                    lv[L].b_index.resize(lv[L].b_index.size() + 2, -1);
-                    HIP_TRY(up_i(cell_rec, &gv.level[L].cell));
-                    HIP_TRY(up_f(lv[L].s_geom, &gv.level[L].sph_geom));
-                    HIP_TRY(up_i(lv[L].s_index, &gv.level[L].sph_index));
-                    HIP_TRY(up_f(lv[L].b_geom, &gv.level[L].box_geom));
-                    HIP_TRY(up_i(lv[L].b_index, &gv.level[L].box_index));
-                    if (getenv("RM_VERBOSE")) {
-                        int longest_list = 0;
-                        for (int c = 0; c < gv.cells; c++)
-                            longest_list = std::max(longest_list, lv[L].s_start[c + 1] - lv[L].s_start[c] + lv[L].b_start[c + 1] - lv[L].b_start[c]);
-                        const size_t entries = lv[L].s_index.size() + lv[L].b_index.size();
+                    e->grid_entries += entries;
+                    if (getenv("RM_VERBOSE"))
                         fprintf(stderr, "rm: spatial index level %d: %d x %d x %d cells of %.3f, base reach %.3f, apron %.3f, %zu entries (%.1f per cell, longest list %d) for %d primitives\n",
                                 L, gv.nx, gv.ny, gv.nz, cell, plans[L].base, apron, entries, (double)entries / gv.cells, longest_list, n_bounded);
-                    }
                 }
+                pool.resize(pool.size() + 16, 0);  // a wave-uniform walk fetches whole groups and pairs
+                if (pool.size() > (size_t)INT32_MAX) return fail(RM_ERR_INVALID, "the spatial index of this scene would not fit 32-bit offsets");
+                HIP_TRY(up_i(pool, &gv.pool));
                 gl.grid = gv;
             }
         }

@@ -82,20 +82,24 @@ typedef GroupedSmall<4, 4, 2> GroupedTierB;
 // point of the cell; a point outside the grid is at least `reach` away from every primitive.
 // There are two sets of lists over the same cells: a short one (the few nearest primitives of the
 // cell), tried first, and a long one (everything within a wider reach).  cells == 0: no index.
+//
+// All of it lives in one pool of dwords, so that a march loop keeps one pointer in scalar registers:
+//   * the cell table of level L at dword 4 * cells * L, one record of four dwords per cell: where the
+//     cell's sphere block starts, where its box block starts (dword offsets into the pool),
+//     sphere count | box count << 16, and the cell's reach (float bits);
+//   * a sphere block: groups of four spheres, 20 dwords each: cx, cy, cz, r of the four, then their
+//     four object indices (the last group is filled up with zeros and -1);
+//   * a box block: eight dwords per box: cx, cy, cz, hx, hy, hz, object index, -.
+// Blocks start at multiples of four dwords; the pool ends with sixteen dwords of padding, since a
+// wave-uniform walk fetches a whole group of spheres or a pair of boxes at once.
 constexpr int kGridLevels = 2;
-struct GridLevel {
-    const int *cell;        // [cells][4]: first sphere entry, first box entry, sphere count | box count << 16, reach (float bits)
-    const float *sph_geom;  // [entries][4]: cx, cy, cz, r
-    const int *sph_index;   // [entries]: object index
-    const float *box_geom;  // [entries][8]: cx, cy, cz, hx, hy, hz, -, -
-    const int *box_index;
-};
+constexpr int kGridSphereGroup = 20;  // dwords per group of four spheres
 struct GridView {
     int nx, ny, nz, cells;
     float ox, oy, oz;   // lower corner
     float inv_cell;     // 1 / edge length
     float reach;        // outside the grid
-    GridLevel level[kGridLevels];
+    const int *pool;
 };
 
 struct GroupedLarge {
@@ -108,6 +112,13 @@ struct GroupedLarge {
     const float *ax[3];  // [n][2]
     const float *gp;     // [n_gp][4]
     const float *box;    // [n_box][8]: cx, cy, cz, hx, hy, hz, -, -
+    // every plane once more, in the order of the fold (X, Y, Z, generic; by object index inside a
+    // group), one 32-byte record each: kind (0, 1, 2 = the axis, 3 = generic) and object index as
+    // bit patterns, then offset, direction (an axis plane) or normal, distance (a generic one).  The
+    // march loops walk this one array: one pointer and one count in scalar registers instead of eight
+    // and four.
+    int n_planes_all;
+    const float *planes_all;
     // Extension: > 0 folds the distances with a smooth minimum instead of the hard one.  The fold
     // runs in the order of the groups (X, Y, Z planes, generic planes, spheres, boxes; by object
     // index within a group), which is part of the definition since the smooth minimum does not
