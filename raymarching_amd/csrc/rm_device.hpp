@@ -988,6 +988,23 @@ RM_DEV void sample_uv_from_pos(int type, const Geom &g, V3 pos, float ms, float 
     }
 }
 
+// How the kernels read the SceneView: through the constant address space.  Nothing writes the view
+// while a kernel runs, and a field read this way arrives by a scalar load (once per wave, through the
+// scalar cache, held in a scalar register) instead of a vector load that every march and every
+// shading pass would wait for; the pointers inside it, coming out of constant memory, are known to
+// point to global memory, so the per-pixel records, luxels and texels behind them are fetched by
+// global loads, not by generic ones.
+typedef const __attribute__((address_space(4))) SceneView &SceneRef;
+RM_DEV SceneRef scene_ref(const SceneView *p) { return *(const __attribute__((address_space(4))) SceneView *)p; }
+// The same view through a copy of its address that the compiler cannot trace back: the fields read
+// after this point are fetched here (a scalar load each, issued together), not at the top of the kernel
+// and carried in scalar registers through the march loops, which have none to spare.
+RM_DEV SceneRef scene_here(SceneRef sv) {
+    const __attribute__((address_space(4))) SceneView *p = &sv;
+    asm volatile("" : "+s"(p));
+    return *p;
+}
+
 // texture.rs:31-37
 RM_DEV V3 texture_sample(const TextureRec &t, float u, float v) {
     float ax = floorf(fabsf(u * t.uscale)), ay = floorf(fabsf(v * t.vscale));
@@ -1011,7 +1028,7 @@ RM_DEV V3 texture_sample(const TextureRec &t, float u, float v) {
 }
 
 // objects.rs:260, 267-274, 294, 314, 336
-RM_DEV V3 object_colour(const SceneView &sv, const ShadeRec &sr, const Geom &g, V3 pos) {
+RM_DEV V3 object_colour(SceneRef sv, const ShadeRec &sr, const Geom &g, V3 pos) {
     if (sr.textured) {
         float u, v;
         sample_uv_from_pos(T_YPLANE, g, pos, (float)sv.map_size, u, v);
@@ -1022,7 +1039,7 @@ RM_DEV V3 object_colour(const SceneView &sv, const ShadeRec &sr, const Geom &g, 
 
 // The four luxels around a sample.  Indices outside the map (the reference aborts on them) are
 // clamped and reported; the check is made once for the four, the clamps only when it fails.
-RM_DEV void luxels4(const SceneView &sv, const float *lm, int u0, int u1, int v0, int v1, bool &oob, V3 &s00, V3 &s01,
+RM_DEV void luxels4(SceneRef sv, const float *lm, int u0, int u1, int v0, int v1, bool &oob, V3 &s00, V3 &s01,
                     V3 &s10, V3 &s11) {
     const int M = sv.map_size;
     const unsigned m = (unsigned)M;
@@ -1051,7 +1068,7 @@ RM_DEV bool no_light(V3 s) {
 
 // objects.rs:45-133 with colour.rs:47-71 (the two sorts there leave the four
 // corners in the order they are passed in, because u0 < u1 and v0 < v1 always).
-RM_DEV V3 sample_lightmap(const SceneView &sv, const ShadeRec &sr, const Geom &g, V3 pos) {
+RM_DEV V3 sample_lightmap(SceneRef sv, const ShadeRec &sr, const Geom &g, V3 pos) {
     const int M = sv.map_size;
     const float *lm = sv.lightmaps + (size_t)sr.lm_slot * M * M * 3;
     float u, v;
@@ -1160,7 +1177,8 @@ struct ShadeResult {
 
 // engine.rs:147-194: everything of shade_object before the reflection branch.
 template <class SC>
-RM_DEV ShadeResult shade_local(const SC &sc, const SceneView &sv, int idx, V3 pos, V3 dir) {
+RM_DEV ShadeResult shade_local(const SC &sc, SceneRef sv_of_kernel, int idx, V3 pos, V3 dir) {
+    SceneRef sv = scene_here(sv_of_kernel);
     const ShadeRec sr = sv.shade[idx];
     const Geom g = sv.geom[idx];
     ShadeResult out;
@@ -1202,7 +1220,7 @@ RM_DEV ShadeResult shade_local(const SC &sc, const SceneView &sv, int idx, V3 po
 // `depth0` = the number of reflective hits already above this ray (0 for a ray from the camera): the
 // chain is cut where the recursion as a whole is MAX_DEPTH deep.
 template <class SC>
-RM_DEV V3 cast_sight_ray(const SC &sc, const SceneView &sv, V3 pos, V3 dir, float first = __builtin_nanf(""),
+RM_DEV V3 cast_sight_ray(const SC &sc, SceneRef sv, V3 pos, V3 dir, float first = __builtin_nanf(""),
                          float first_sph = __builtin_nanf(""), int depth0 = 0) {
     // (The frames live in private memory, 28 bytes each: their writes are what the kernel's HBM write
     // traffic has beyond the pixels.  Keeping the first frame - the only one most reflecting pixels ever
@@ -1280,7 +1298,7 @@ RM_DEV V3 internal_march(int type, const Geom &g, V3 pos, V3 dir) {
 // starts at shade_object for that object at `pos` instead of marching (engine.rs:147).
 constexpr float REFRACTION_IOR = 2.5f;
 template <class SC>
-RM_DEV V3 cast_sight_tree(const SC &sc, const SceneView &sv, V3 pos, V3 dir, int first_hit = -1,
+RM_DEV V3 cast_sight_tree(const SC &sc, SceneRef sv, V3 pos, V3 dir, int first_hit = -1,
                           float first = __builtin_nanf(""), float first_sph = __builtin_nanf("")) {
     struct Frame {
         V3 acc, oc;       // the hit's colour so far (engine.rs:194, then :225 added); its object colour

@@ -36,7 +36,7 @@ static_assert(TILE == RM_STRIP_ROWS, "a strip is one row of wave tiles");
 constexpr int BLOCK_THREADS = 64;
 
 struct RenderArgs {
-    const SceneView *sv;  // device memory: read where needed, not held in registers
+    const SceneView *sv;  // device memory: read where needed (scene_ref: by scalar loads)
     Pose pose;
     int row_begin, row_end;
     int blocks_x, blocks_y;
@@ -221,7 +221,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, const G &g) {
     V3 dir = pixel_direction(a.pose, x, y_inv, a.screen_u, a.screen_v);
     V3 cam = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
     diag_lap(DG_SETUP);
-    V3 colour = cast_sight_ray(acc_of(g), *a.sv, cam, dir, a.camera_dist, a.camera_sph);
+    V3 colour = cast_sight_ray(acc_of(g), scene_ref(a.sv), cam, dir, a.camera_dist, a.camera_sph);
     diag_lap(DG_REFLECT);
 #ifdef RM_DIAG
     __syncthreads();
@@ -313,8 +313,15 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, const G &g) {
 #endif
 }
 
+// (The plain frame kernel of the small tiers is held to the 72 registers of seven waves: left alone
+// the compiler takes 74-77 since the shading's loads went global and more of them fly at once, and a
+// sixth of the wave slots would go for nothing.)
 template <class G>
-__global__ __launch_bounds__(BLOCK_THREADS, MinWaves<G>::value) void render_kernel(const RenderArgs a, const G g) {
+struct MinWavesFrame {
+    static constexpr int value = MinWaves<G>::value > 7 ? MinWaves<G>::value : 7;
+};
+template <class G>
+__global__ __launch_bounds__(BLOCK_THREADS, MinWavesFrame<G>::value) void render_kernel(const RenderArgs a, const G g) {
     render_tile(a, g);
 }
 
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_primary_kernel(const Ren
     int x, y_inv, out_row;
     tile_pixel(a, x, y_inv, out_row);
     if (x >= a.pose.W || y_inv >= a.row_end) return;
-    const SceneView &sv = *a.sv;
+    SceneRef sv = scene_ref(a.sv);
     V3 dir = pixel_direction(a.pose, x, y_inv, a.screen_u, a.screen_v);
     V3 pos = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
     int steps;
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_primary_kernel(const Ren
 
 template <class G>
 __global__ __launch_bounds__(BLOCK_THREADS) void render_reflect_kernel(const RenderArgs a, const ReflectQueue q, const G g) {
-    const SceneView &sv = *a.sv;
+    SceneRef sv = scene_ref(a.sv);
     const unsigned count = *q.count;
     for (unsigned i = blockIdx.x * BLOCK_THREADS + threadIdx.x; i < count; i += gridDim.x * BLOCK_THREADS) {
         float v[14];
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, MinWaves<G>::value) void render_ssaa
     V3 sum = v3(0.0f, 0.0f, 0.0f);
     for (int i = 0; i < 4; i++) {
         const V3 off = i == 0 ? v3(ox, 0.0f, 0.0f) : i == 1 ? v3(-ox, 0.0f, 0.0f) : i == 2 ? v3(0.0f, oy, 0.0f) : v3(0.0f, -oy, 0.0f);
-        const V3 c = cast_sight_ray(acc_of(g), *a.sv, cam, normalized(dir + off), a.camera_dist, a.camera_sph);
+        const V3 c = cast_sight_ray(acc_of(g), scene_ref(a.sv), cam, normalized(dir + off), a.camera_dist, a.camera_sph);
         sum = i == 0 ? c : sum + c;
     }
     unsigned px = pack_pixel(sum / 4.0f, a.pose.exposure);
@@ -445,12 +452,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, MinWaves<G>::value) void render_tree
         V3 sum = v3(0.0f, 0.0f, 0.0f);
         for (int i = 0; i < 4; i++) {
             const V3 off = i == 0 ? v3(ox, 0.0f, 0.0f) : i == 1 ? v3(-ox, 0.0f, 0.0f) : i == 2 ? v3(0.0f, oy, 0.0f) : v3(0.0f, -oy, 0.0f);
-            const V3 c = cast_sight_tree(acc_of(g), *a.sv, cam, normalized(dir + off), -1, a.camera_dist, a.camera_sph);
+            const V3 c = cast_sight_tree(acc_of(g), scene_ref(a.sv), cam, normalized(dir + off), -1, a.camera_dist, a.camera_sph);
             sum = i == 0 ? c : sum + c;
         }
         colour = sum / 4.0f;
     } else {
-        colour = cast_sight_tree(acc_of(g), *a.sv, cam, dir, -1, a.camera_dist, a.camera_sph);
+        colour = cast_sight_tree(acc_of(g), scene_ref(a.sv), cam, dir, -1, a.camera_dist, a.camera_sph);
     }
     *reinterpret_cast<unsigned *>(a.out + (size_t)out_row * a.pitch + (size_t)x * 4) = pack_pixel(colour, a.pose.exposure);
 }
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_kernel(const RenderArgs a
     V3 pos = v3(a.pose.cam[0], a.pose.cam[1], a.pose.cam[2]);
     int steps;
     bool capped;
-    int idx = march(acc_of(g), pos, dir, -1, a.sv->march_cap, steps, capped, a.camera_dist, a.camera_sph);
+    int idx = march(acc_of(g), pos, dir, -1, scene_ref(a.sv).march_cap, steps, capped, a.camera_dist, a.camera_sph);
     size_t i = (size_t)y_inv * a.pose.W + x;
     if (hit) hit[i] = idx;
     if (steps_out) steps_out[i] = steps;
@@ -483,7 +490,7 @@ __global__ void probe_shade_kernel(const SceneView *svp, int n, const int *obj, 
                                    float *out, const G g) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const SceneView &sv = *svp;
+    SceneRef sv = scene_ref(svp);
     V3 p = v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
     V3 d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
     int idx = obj[i];
@@ -551,7 +558,7 @@ __global__ void rad_cloud_kernel(const RadArgs a) {
     V3 pos = v3(a.pos[3 * p], a.pos[3 * p + 1], a.pos[3 * p + 2]);
     const ShadeRec sr = a.sv->shade[obj];
     const Geom g = a.sv->geom[obj];
-    V3 c = object_colour(*a.sv, sr, g, pos);
+    V3 c = object_colour(scene_ref(a.sv), sr, g, pos);
     V3 n = calculate_normal(sr.type, g, pos, a.sv->tetra_normals != 0);
     a.col[3 * p] = c.x;
     a.col[3 * p + 1] = c.y;
