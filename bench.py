@@ -211,14 +211,15 @@ def radiosity_workload(args, world, rank, local_rank, backend):
     n = 8 * M * M
     phase_ms = {"form_factors": 0.0, "bounces": 0.0}
 
-    def step(timed):
+    def step():
         if gathering:
             group.compute_lightmaps(4)
-            return
-        if not timed:
+        else:
             eng.compute_lightmaps(4)
-            return
-        # the same calls rm_engine_compute_lightmaps makes, with events between the phases (null stream)
+
+    def phases():
+        # the stepwise calls (what a patch-sharded host makes), with events between the phases (null
+        # stream): the kernels' own times for the roofline, taken after the timed region
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         eng.radiosity_begin()
         ev[0].record()
@@ -240,13 +241,16 @@ def radiosity_workload(args, world, rank, local_rank, backend):
         torch.cuda.synchronize()
 
     for _ in range(warmup):
-        step(False)
+        step()
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step(True)
+        step()
     fence()
     elapsed = time.perf_counter() - t0
+    if not gathering:
+        for _ in range(steps):
+            phases()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

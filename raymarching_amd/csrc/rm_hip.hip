@@ -568,11 +568,9 @@ __global__ void rad_cloud_kernel(const RadArgs a) {
     a.nrm[3 * p + 2] = n.z;
 }
 
-// radiosity.rs:52-101
+// radiosity.rs:52-101 for one patch
 template <class G>
-__global__ void rad_direct_kernel(const RadArgs a, const G grp) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.n_patches) return;
+__device__ __forceinline__ void rad_direct_patch(const RadArgs &a, const G &grp, int p) {
     const int mm = a.sv->map_size * a.sv->map_size;
     int obj = a.patch_obj[p / mm];
     const ShadeRec sr = a.sv->shade[obj];
@@ -601,14 +599,28 @@ __global__ void rad_direct_kernel(const RadArgs a, const G grp) {
     a.lightmaps[3 * p + 1] = lm.y;
     a.lightmaps[3 * p + 2] = lm.z;
 }
+template <class G>
+__global__ void rad_direct_kernel(const RadArgs a, const G grp) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_patches) return;
+    rad_direct_patch(a, grp, p);
+}
 
 // radiosity.rs:119-152 for one (receiver i, source j) pair: everything of the
 // inner loop that does not depend on the bounce.  x = receiver, y = source.
+// `direct` = 1: the launch has one more row of workgroups, its first, and that row does the direct
+// lighting of the receivers instead (rad_direct_patch: it reads the clouds like this kernel and writes
+// the emissive map and the lightmaps, which this kernel does not touch) - a few waves, each one long
+// march, that would otherwise be a launch of their own with the machine all but empty.
 template <class G>
-__global__ void rad_form_kernel(const RadArgs a, int p0, int p1, int j0, const G grp) {
+__global__ void rad_form_kernel(const RadArgs a, int p0, int p1, int j0, int direct, const G grp) {
     int i = p0 + blockIdx.x * blockDim.x + threadIdx.x;
-    int j = j0 + blockIdx.y;
     if (i >= p1) return;
+    if (direct && blockIdx.y == 0) {
+        rad_direct_patch(a, grp, i);
+        return;
+    }
+    int j = j0 + (int)blockIdx.y - direct;
     const int mm = a.sv->map_size * a.sv->map_size;
     float f = -1.0f;
     if (i / mm != j / mm) {  // radiosity.rs:112: no self illumination
@@ -2321,7 +2333,9 @@ int rm_engine_probe_pack(rm_engine *e, int n, const float *linear, float exposur
 }  // extern "C" (the steps below are shared by the allocating and the non-allocating entry points)
 
 // engine.rs:259-288: clouds and direct lighting of every patch into `b`.
-static int rad_begin_on(rm_engine *e, const RadBuffers &b) {
+// (`direct` = false leaves the direct lighting to the form-factor launch that follows: rad_form_on
+// with `direct` = true over every patch.)
+static int rad_begin_on(rm_engine *e, const RadBuffers &b, bool direct = true) {
     const int NP = e->n_patches;
     if (NP == 0) return RM_OK;
     if (!e->sample_pos_ok) return fail(RM_ERR_UNSUPPORTED, "object type has no lightmap parameterisation");
@@ -2329,22 +2343,26 @@ static int rad_begin_on(rm_engine *e, const RadBuffers &b) {
     RadArgs a = e->rad_args(b);
     dim3 grid((NP + 63) / 64);
     hipLaunchKernelGGL(rad_cloud_kernel, grid, dim3(64), 0, e->stream, a);
-    RM_LAUNCH(rad_direct_kernel, e, grid, dim3(64), a);
+    if (direct) RM_LAUNCH(rad_direct_kernel, e, grid, dim3(64), a);
     HIP_TRY(hipGetLastError());
     return RM_OK;
 }
 
-static int rad_form_on(rm_engine *e, const RadBuffers &b, int p0, int p1) {
+static int rad_form_on(rm_engine *e, const RadBuffers &b, int p0, int p1, bool direct = false) {
     if (p0 == p1) return RM_OK;
     const int NP = e->n_patches;
+    if (direct && (p0 != 0 || p1 != NP)) return fail(RM_ERR_INVALID, "direct lighting rides on a form-factor launch over every patch only");
     RadArgs a = e->rad_args(b);
-    // sources go into the grid's y dimension, 65535 at most per launch (RM_RAD_CHUNK: test hook)
+    // sources go into the grid's y dimension, 65535 rows at most per launch (RM_RAD_CHUNK: test hook)
     int chunk = 65535;
-    if (const char *c = getenv("RM_RAD_CHUNK")) chunk = std::max(1, std::min(65535, atoi(c)));
-    for (int j0 = 0; j0 < NP; j0 += chunk) {
-        dim3 grid((p1 - p0 + 63) / 64, std::min(chunk, NP - j0));
-        RM_LAUNCH(rad_form_kernel, e, grid, dim3(64), a, p0, p1, j0);
+    if (const char *c = getenv("RM_RAD_CHUNK")) chunk = std::max(2, std::min(65535, atoi(c)));
+    for (int j0 = 0; j0 < NP;) {
+        const int extra = direct && j0 == 0 ? 1 : 0;  // the first launch's first row
+        const int rows = std::min(chunk - extra, NP - j0);
+        dim3 grid((p1 - p0 + 63) / 64, rows + extra);
+        RM_LAUNCH(rad_form_kernel, e, grid, dim3(64), a, p0, p1, j0, extra);
         HIP_TRY(hipGetLastError());
+        j0 += rows;
     }
     return RM_OK;
 }
@@ -2433,20 +2451,42 @@ int rm_engine_radiosity_buffers(rm_engine *e, void **d_next_emissive, void **d_l
     return RM_OK;
 }
 
-int rm_engine_compute_lightmaps(rm_engine *e, int bounces) {
-    if (!e || bounces < 0) return fail(RM_ERR_INVALID, "bad argument");
-    int rc = rm_engine_radiosity_begin(e);
+// The whole precompute on one GPU, shared by the two entry points below.  Against the stepwise calls
+// (which patch sharding needs) it saves launches: the direct lighting rides on the form-factor launch,
+// and a bounce over every patch rewrites the whole of emissive_next, so the two emissive maps trade
+// places from bounce to bounce instead of being copied (rm_engine_radiosity_commit).  Returns with
+// the latest emissive values in `b.emissive`.
+static int rad_whole_on(rm_engine *e, RadBuffers &b, int bounces) {
+    const int NP = e->n_patches;
+    int rc = rad_begin_on(e, b, bounces == 0);
     if (rc) return rc;
     if (bounces > 0) {
-        rc = rm_engine_radiosity_form_factors(e, 0, e->n_patches);
+        rc = rad_form_on(e, b, 0, NP, true);
         if (rc) return rc;
     }
-    for (int b = 0; b < bounces; b++) {
-        rc = rm_engine_radiosity_bounce(e, 0, e->n_patches);
+    for (int k = 0; k < bounces; k++) {
+        rc = rad_bounce_on(e, b, 0, NP);
         if (rc) return rc;
-        rc = rm_engine_radiosity_commit(e);
-        if (rc) return rc;
+        std::swap(b.emissive, b.emissive_next);
     }
+    return RM_OK;
+}
+
+int rm_engine_compute_lightmaps(rm_engine *e, int bounces) {
+    if (!e || bounces < 0) return fail(RM_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    if (int rc_ = sync_view(e)) return rc_;
+    if (int rc_ = quiesce_frames_in_flight(e)) return rc_;  // the precompute rewrites the lightmaps they sample
+    const int NP = e->n_patches;
+    if (!e->rad.col) {
+        HIP_TRY(dev_alloc(&e->rad.col, (size_t)NP * 3));
+        HIP_TRY(dev_alloc(&e->rad.nrm, (size_t)NP * 3));
+        HIP_TRY(dev_alloc(&e->rad.emissive, (size_t)NP * 3));
+        HIP_TRY(dev_alloc(&e->rad.emissive_next, (size_t)NP * 3));
+    }
+    if (bounces > 0 && !e->rad.ft) HIP_TRY(dev_alloc(&e->rad.ft, (size_t)NP * NP));
+    e->rad_begun = true;
+    if (int rc = rad_whole_on(e, e->rad, bounces)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     return RM_OK;
 }
@@ -2473,18 +2513,8 @@ int rm_engine_compute_lightmaps_static(rm_engine *e, int bounces) {
     b.emissive = b.nrm + cloud;
     b.emissive_next = b.emissive + cloud;
     b.ft = b.emissive_next + cloud;
-    int rc = rad_begin_on(e, b);  // writes every cloud entry and zeroes emissive_next; FT is written in full below
-    if (rc) return rc;
-    if (bounces > 0) {
-        rc = rad_form_on(e, b, 0, NP);
-        if (rc) return rc;
-    }
-    for (int k = 0; k < bounces; k++) {
-        rc = rad_bounce_on(e, b, 0, NP);
-        if (rc) return rc;
-        rc = rad_commit_on(e, b);
-        if (rc) return rc;
-    }
+    // (writes every cloud entry and zeroes emissive_next; FT is written in full)
+    if (int rc = rad_whole_on(e, b, bounces)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     return RM_OK;
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 measurement session (run on the GPU box from the repo root: bash tools/gpu_session2.sh <tag>):
+# Measurement session (run on the GPU box from the repo root: bash tools/gpu_session2.sh <tag>):
 # bench lines of every configuration, rocprofv3 kernel traces of the same commands, PMC passes (each
 # in a run of its own) for the render kernel at 4K, the FXAA kernel, the stress kernel and the
 # radiosity kernels.  Results under gpurun_out/<tag>/; the summaries are copied to profiles/ by hand.
