@@ -671,13 +671,22 @@ __global__ void rad_form_kernel(const RadArgs a, int p0, int p1, int j0, int dir
 // on it.
 template <int CHUNK>
 __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0, int p1) {
-    __shared__ float slab[CHUNK][64];
-    __shared__ float em_s[CHUNK * 3];
-    constexpr int kPerThread = CHUNK / 4;             // rows of a slab each thread fetches
+    // The slab lies receiver-major in LDS, a receiver's CHUNK sources side by side (rows of CHUNK + 4
+    // words: 16-byte aligned, and sixteen lanes' 16-byte accesses fall on all 64 banks once), and the
+    // emissive values channel-major: a fold step's operands then come four sources to a 16-byte read -
+    // eight reads per sixteen sources where single words took thirty-two, and for the lone wave per
+    // SIMD that folds a small map those reads are most of a bounce's time.
+    constexpr int kStride = CHUNK + 4;
+    __shared__ __attribute__((aligned(16))) float slab[64][kStride];
+    __shared__ __attribute__((aligned(16))) float em_s[3][CHUNK];
+    constexpr int kGroups = CHUNK / 16;               // groups of four rows of a slab each thread fetches
+    constexpr int kPerThread = 4 * kGroups;
     constexpr int kEmPerThread = (CHUNK * 3 + 255) / 256;  // emissive values of a slab each thread fetches
     const int NP = a.n_patches;
     const int i0 = p0 + blockIdx.x * 64;
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;  // part: row phase when loading, channel when summing
+    // part: row-group phase when loading, channel when summing; the same in every lane of a wave, and
+    // said so, so that the row numbers and row addresses below are worked out on the scalar unit
+    const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = i0 + lane;
     const bool valid = i < p1;
     // The next slab travels from memory into registers while the current one is folded, so a fold
@@ -687,10 +696,14 @@ __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0
     // Every load of a fetch is issued unconditionally, at an address clamped into the arrays: a load
     // under a condition becomes a branch with a wait behind it, and the fetches of a slab would go to
     // memory one after the other.  What a clamped load brought is discarded when the slab is stored.
+    // Thread (part, lane) fetches rows 4g .. 4g+3 for g = part, part + 4, ...: each load is a row
+    // segment of 64 receivers, and the four values of a group leave for LDS in one 16-byte store.
     const int ic = min(i, NP - 1);
     const auto fetch = [&](int j0) {
 #pragma unroll
-        for (int k = 0; k < kPerThread; k++) pre[k] = a.ft[(size_t)min(j0 + part + 4 * k, NP - 1) * NP + ic];
+        for (int k = 0; k < kGroups; k++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) pre[4 * k + q] = a.ft[(size_t)min(j0 + 4 * (part + 4 * k) + q, NP - 1) * NP + ic];
 #pragma unroll
         for (int k = 0; k < kEmPerThread; k++) em_pre[k] = a.emissive[min(3 * j0 + (int)threadIdx.x + 256 * k, 3 * NP - 1)];
     };
@@ -699,32 +712,45 @@ __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0
     for (int j0 = 0; j0 < NP; j0 += CHUNK) {
         const int rows = min(CHUNK, NP - j0);
 #pragma unroll
-        for (int k = 0; k < kPerThread; k++) {
-            // a pair that contributes nothing (-1), a row beyond the last source, a receiver beyond p1: emission * 0 = +0
-            const bool counts = valid && part + 4 * k < rows && !(pre[k] == -1.0f);
-            slab[part + 4 * k][lane] = counts ? pre[k] : 0.0f;
+        for (int k = 0; k < kGroups; k++) {
+            const int row = 4 * (part + 4 * k);
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                // a pair that contributes nothing (-1), a row beyond the last source, a receiver beyond p1: emission * 0 = +0
+                const bool counts = valid && row + q < rows && !(pre[4 * k + q] == -1.0f);
+                v[q] = counts ? pre[4 * k + q] : 0.0f;
+            }
+            *reinterpret_cast<float4 *>(&slab[lane][row]) = make_float4(v[0], v[1], v[2], v[3]);
         }
 #pragma unroll
         for (int k = 0; k < kEmPerThread; k++) {
             const int t = (int)threadIdx.x + 256 * k;
-            if (t < CHUNK * 3) em_s[t] = t < rows * 3 ? em_pre[k] : 0.0f;
+            if (t < CHUNK * 3) em_s[t % 3][t / 3] = t < rows * 3 ? em_pre[k] : 0.0f;
         }
         __syncthreads();
         if (j0 + CHUNK < NP) fetch(j0 + CHUNK);
         if (part < 3 && valid) {
             // The additions form one dependent chain per receiver and channel; everything else of a
-            // step - the two reads from the slab and the product - does not depend on the sum so far.
+            // step - the reads from the slab and the product - does not depend on the sum so far.
             // Sixteen steps at a time: their operands are fetched and multiplied first, then added in
             // source order, so that a step costs one addition's latency and not a round trip to LDS.
             int jj = 0;
             for (; jj + 16 <= rows; jj += 16) {
                 float term[16];
 #pragma unroll
-                for (int u = 0; u < 16; u++) term[u] = em_s[3 * (jj + u) + part] * slab[jj + u][lane];
+                for (int u = 0; u < 4; u++) {
+                    const float4 e = *reinterpret_cast<const float4 *>(&em_s[part][jj + 4 * u]);
+                    const float4 f = *reinterpret_cast<const float4 *>(&slab[lane][jj + 4 * u]);
+                    term[4 * u] = e.x * f.x;
+                    term[4 * u + 1] = e.y * f.y;
+                    term[4 * u + 2] = e.z * f.z;
+                    term[4 * u + 3] = e.w * f.w;
+                }
 #pragma unroll
                 for (int u = 0; u < 16; u++) acc = acc + term[u];
             }
-            for (; jj < rows; jj++) acc = acc + em_s[3 * jj + part] * slab[jj][lane];
+            for (; jj < rows; jj++) acc = acc + em_s[part][jj] * slab[lane][jj];
         }
         __syncthreads();
     }
@@ -2371,10 +2397,13 @@ static int rad_bounce_on(rm_engine *e, const RadBuffers &b, int p0, int p1) {
     if (p0 == p1) return RM_OK;
     RadArgs a = e->rad_args(b);
     dim3 grid((p1 - p0 + 63) / 64);
-    // fewer than eight workgroups per compute unit: deeper slabs, so that as many bytes stay in flight
+    // Slabs of 128 sources (four workgroups per compute unit) - except where 192 (three per unit) still
+    // hold every workgroup of the launch at once and each unit has at least one: more bytes in flight
+    // per workgroup, and no second round to wait for (MAP_SIZE 64, 512 workgroups: 0.73 against 0.78 ms;
+    // smaller launches are bound by the fold's latency and larger ones by rounds, both better at 128).
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
-    int chunk = 128;
+    int chunk = ((int)grid.x >= cus && (int)grid.x <= 3 * cus) ? 192 : 128;
     if (const char *c = getenv("RM_BOUNCE_CHUNK")) chunk = atoi(c);  // tuning aid
     if (chunk == 64)
         hipLaunchKernelGGL(rad_bounce_kernel<64>, grid, dim3(256), 0, e->stream, a, p0, p1);
