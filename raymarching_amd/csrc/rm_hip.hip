@@ -613,6 +613,36 @@ __global__ void rad_direct_kernel(const RadArgs a, const G grp) {
 // the emissive map and the lightmaps, which this kernel does not touch) - a few waves, each one long
 // march, that would otherwise be a launch of their own with the machine all but empty.
 template <class G>
+__device__ __forceinline__ float rad_form_pair(const RadArgs &a, const G &grp, int j, int recv_obj, V3 sample_pos, V3 sample_n) {
+    V3 src = v3(a.pos[3 * j], a.pos[3 * j + 1], a.pos[3 * j + 2]);
+    V3 src_n = v3(a.nrm[3 * j], a.nrm[3 * j + 1], a.nrm[3 * j + 2]);
+    V3 to_light = src - sample_pos;
+    float dist = mag(to_light);
+    to_light = to_light / dist;
+    // radiosity.rs:147-152: what the pair contributes per unit of emission if nothing is in the way
+    const float att = dot(sample_n, to_light) * -dot(src_n, to_light);
+    const float diffuse = rs_max(att, 0.0f) / (dist * dist);
+    const float open = rs_min(diffuse, 2.0f);
+    // A pair that faces away contributes emission * 0 if it is open and nothing if it is blocked:
+    // +0 or -0 added to a sum that started at +0 leaves it as it is either way (emission values are
+    // finite), so the occlusion march is run only where its outcome can show.  A wave whose 64
+    // receivers all face away from the source skips it altogether.
+    const bool matters = !(open == 0.0f);
+    float f = open;
+    if (wave_any(matters)) {
+        if (matters) {
+            V3 back = -to_light;
+            V3 rp = src + back * (3.0f * SMALL_DISTANCE);  // radiosity.rs:131
+            int steps;
+            bool capped;
+            int hit = march(acc_of(grp), rp, back, -1, 0, steps, capped);
+            bool blocked = (hit >= 0) && (hit != recv_obj) && (mag_sqd(rp - sample_pos) > 0.1f * 0.1f);
+            if (blocked) f = -1.0f;
+        }
+    }
+    return f;
+}
+template <class G>
 __global__ void rad_form_kernel(const RadArgs a, int p0, int p1, int j0, int direct, const G grp) {
     int i = p0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p1) return;
@@ -627,34 +657,28 @@ __global__ void rad_form_kernel(const RadArgs a, int p0, int p1, int j0, int dir
         int recv_obj = a.patch_obj[i / mm];
         V3 sample_pos = v3(a.pos[3 * i], a.pos[3 * i + 1], a.pos[3 * i + 2]);
         V3 sample_n = v3(a.nrm[3 * i], a.nrm[3 * i + 1], a.nrm[3 * i + 2]);
-        V3 src = v3(a.pos[3 * j], a.pos[3 * j + 1], a.pos[3 * j + 2]);
-        V3 src_n = v3(a.nrm[3 * j], a.nrm[3 * j + 1], a.nrm[3 * j + 2]);
-        V3 to_light = src - sample_pos;
-        float dist = mag(to_light);
-        to_light = to_light / dist;
-        // radiosity.rs:147-152: what the pair contributes per unit of emission if nothing is in the way
-        const float att = dot(sample_n, to_light) * -dot(src_n, to_light);
-        const float diffuse = rs_max(att, 0.0f) / (dist * dist);
-        const float open = rs_min(diffuse, 2.0f);
-        // A pair that faces away contributes emission * 0 if it is open and nothing if it is blocked:
-        // +0 or -0 added to a sum that started at +0 leaves it as it is either way (emission values are
-        // finite), so the occlusion march is run only where its outcome can show.  A wave whose 64
-        // receivers all face away from the source skips it altogether.
-        const bool matters = !(open == 0.0f);
-        f = open;
-        if (wave_any(matters)) {
-            if (matters) {
-                V3 back = -to_light;
-                V3 rp = src + back * (3.0f * SMALL_DISTANCE);  // radiosity.rs:131
-                int steps;
-                bool capped;
-                int hit = march(acc_of(grp), rp, back, -1, 0, steps, capped);
-                bool blocked = (hit >= 0) && (hit != recv_obj) && (mag_sqd(rp - sample_pos) > 0.1f * 0.1f);
-                if (blocked) f = -1.0f;
-            }
-        }
+        f = rad_form_pair(a, grp, j, recv_obj, sample_pos, sample_n);
     }
     a.ft[(size_t)j * a.n_patches + i] = f;
+}
+// The same with `per` sources per workgroup, one after the other: what a wave sets up - the scene in
+// scalar registers, its receivers' points and normals - then serves several marches.  For launches
+// that take every wave slot of the machine many times over; a small map needs every wave it can get,
+// one source each (the kernel above).
+template <class G>
+__global__ void rad_form_multi_kernel(const RadArgs a, int p0, int p1, int j0, int j1, int per, const G grp) {
+    int i = p0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p1) return;
+    const int jb = j0 + (int)blockIdx.y * per, je = min(jb + per, j1);
+    const int mm = scene_ref(a.sv).map_size * scene_ref(a.sv).map_size;
+    const int recv_obj = a.patch_obj[i / mm];
+    const V3 sample_pos = v3(a.pos[3 * i], a.pos[3 * i + 1], a.pos[3 * i + 2]);
+    const V3 sample_n = v3(a.nrm[3 * i], a.nrm[3 * i + 1], a.nrm[3 * i + 2]);
+    for (int j = jb; j < je; j++) {
+        float f = -1.0f;
+        if (i / mm != j / mm) f = rad_form_pair(a, grp, j, recv_obj, sample_pos, sample_n);  // radiosity.rs:112
+        a.ft[(size_t)j * a.n_patches + i] = f;
+    }
 }
 
 // radiosity.rs:107-156 + 184-192 for 64 receivers per workgroup: the ordered sums over sources.
@@ -2382,11 +2406,32 @@ static int rad_form_on(rm_engine *e, const RadBuffers &b, int p0, int p1, bool d
     // sources go into the grid's y dimension, 65535 rows at most per launch (RM_RAD_CHUNK: test hook)
     int chunk = 65535;
     if (const char *c = getenv("RM_RAD_CHUNK")) chunk = std::max(2, std::min(65535, atoi(c)));
+    // Sources per workgroup: one while the launch has few waves (its longest march bounds it), more
+    // once every wave slot of the machine is taken many times over - as many as leave a quarter of a
+    // million workgroups, sixteen at most (MAP_SIZE 32: 0.99 -> 0.89 ms with four, 64: 11.5 -> 10.3 ms
+    // with sixteen; the matrix is the same bit for bit, each pair is computed as before).
+    int per = 1;
+    while (per < 16 && (long)((p1 - p0 + 63) / 64) * NP / (2 * per) >= 250000) per *= 2;
+    if (const char *c = getenv("RM_RAD_PER")) per = std::max(1, std::min(64, atoi(c)));  // tuning aid
+    if (per == 1) {
+        for (int j0 = 0; j0 < NP;) {
+            const int extra = direct && j0 == 0 ? 1 : 0;  // the first launch's first row
+            const int rows = std::min(chunk - extra, NP - j0);
+            dim3 grid((p1 - p0 + 63) / 64, rows + extra);
+            RM_LAUNCH(rad_form_kernel, e, grid, dim3(64), a, p0, p1, j0, extra);
+            HIP_TRY(hipGetLastError());
+            j0 += rows;
+        }
+        return RM_OK;
+    }
+    if (direct) {  // (a launch of its own here: the machine is busy for milliseconds either way)
+        RM_LAUNCH(rad_direct_kernel, e, dim3((NP + 63) / 64), dim3(64), a);
+        HIP_TRY(hipGetLastError());
+    }
     for (int j0 = 0; j0 < NP;) {
-        const int extra = direct && j0 == 0 ? 1 : 0;  // the first launch's first row
-        const int rows = std::min(chunk - extra, NP - j0);
-        dim3 grid((p1 - p0 + 63) / 64, rows + extra);
-        RM_LAUNCH(rad_form_kernel, e, grid, dim3(64), a, p0, p1, j0, extra);
+        const int rows = (int)std::min((long)chunk * per, (long)(NP - j0));
+        dim3 grid((p1 - p0 + 63) / 64, (rows + per - 1) / per);
+        RM_LAUNCH(rad_form_multi_kernel, e, grid, dim3(64), a, p0, p1, j0, j0 + rows, per);
         HIP_TRY(hipGetLastError());
         j0 += rows;
     }
