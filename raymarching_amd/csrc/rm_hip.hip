@@ -553,13 +553,13 @@ struct RadArgs {
 __global__ void rad_cloud_kernel(const RadArgs a) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.n_patches) return;
-    const int mm = a.sv->map_size * a.sv->map_size;
+    const int mm = scene_ref(a.sv).map_size * scene_ref(a.sv).map_size;
     int obj = a.patch_obj[p / mm];
     V3 pos = v3(a.pos[3 * p], a.pos[3 * p + 1], a.pos[3 * p + 2]);
-    const ShadeRec sr = a.sv->shade[obj];
-    const Geom g = a.sv->geom[obj];
+    const ShadeRec sr = scene_ref(a.sv).shade[obj];
+    const Geom g = scene_ref(a.sv).geom[obj];
     V3 c = object_colour(scene_ref(a.sv), sr, g, pos);
-    V3 n = calculate_normal(sr.type, g, pos, a.sv->tetra_normals != 0);
+    V3 n = calculate_normal(sr.type, g, pos, scene_ref(a.sv).tetra_normals != 0);
     a.col[3 * p] = c.x;
     a.col[3 * p + 1] = c.y;
     a.col[3 * p + 2] = c.z;
@@ -571,13 +571,13 @@ __global__ void rad_cloud_kernel(const RadArgs a) {
 // radiosity.rs:52-101 for one patch
 template <class G>
 __device__ __forceinline__ void rad_direct_patch(const RadArgs &a, const G &grp, int p) {
-    const int mm = a.sv->map_size * a.sv->map_size;
+    const int mm = scene_ref(a.sv).map_size * scene_ref(a.sv).map_size;
     int obj = a.patch_obj[p / mm];
-    const ShadeRec sr = a.sv->shade[obj];
-    const Geom g = a.sv->geom[obj];
+    const ShadeRec sr = scene_ref(a.sv).shade[obj];
+    const Geom g = scene_ref(a.sv).geom[obj];
     V3 origin = v3(a.pos[3 * p], a.pos[3 * p + 1], a.pos[3 * p + 2]);
     V3 colour = v3(a.col[3 * p], a.col[3 * p + 1], a.col[3 * p + 2]);
-    V3 light = v3(a.sv->light[0], a.sv->light[1], a.sv->light[2]);
+    V3 light = v3(scene_ref(a.sv).light[0], scene_ref(a.sv).light[1], scene_ref(a.sv).light[2]);
     V3 to_light = light - origin;
     float dist = mag(to_light);
     to_light = to_light / dist;
@@ -587,8 +587,8 @@ __device__ __forceinline__ void rad_direct_patch(const RadArgs &a, const G &grp,
     march(acc_of(grp), rp, to_light, obj, 0, steps, capped);
     V3 em = v3(0.0f, 0.0f, 0.0f), lm = v3(0.0f, 0.0f, 0.0f);
     if (!(mag(rp - origin) < (dist + 3.0f * SMALL_DISTANCE))) {
-        V3 n = calculate_normal(sr.type, g, origin, a.sv->tetra_normals != 0);
-        float diffuse = rs_max(dot(n, to_light), 0.0f) * a.sv->intensity / (dist * dist);
+        V3 n = calculate_normal(sr.type, g, origin, scene_ref(a.sv).tetra_normals != 0);
+        float diffuse = rs_max(dot(n, to_light), 0.0f) * scene_ref(a.sv).intensity / (dist * dist);
         em = colour * (diffuse + sr.emissive);
         lm = colour * sr.emissive;
     }
@@ -651,7 +651,7 @@ __global__ void rad_form_kernel(const RadArgs a, int p0, int p1, int j0, int dir
         return;
     }
     int j = j0 + (int)blockIdx.y - direct;
-    const int mm = a.sv->map_size * a.sv->map_size;
+    const int mm = scene_ref(a.sv).map_size * scene_ref(a.sv).map_size;
     float f = -1.0f;
     if (i / mm != j / mm) {  // radiosity.rs:112: no self illumination
         int recv_obj = a.patch_obj[i / mm];
