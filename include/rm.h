@@ -159,7 +159,7 @@ int rm_engine_radiosity_buffers(rm_engine *engine, void **d_next_emissive, void 
 /* rm_engine_compute_lightmaps for callers that cannot allocate device memory (code under HIP graph
  * capture set-up, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
  * reference.  Same kernels, same result bit for bit; the clouds, the emissive maps and the
- * form-factor matrix live in a static device array of the library (4.05 MiB per GPU, held until the
+ * form-factor matrix live in a static device array of the library (4.10 MiB per GPU, held until the
  * process ends) instead of buffers allocated on first use, and the call allocates nothing.
  * Limit: map_size^2 * lightmapped objects <= RM_STATIC_MAX_PATCHES, else RM_ERR_LIMIT.  Every engine
  * on one GPU shares that GPU's array: calls that overlap on one GPU race (calls on different GPUs do

@@ -533,7 +533,7 @@ __global__ void probe_pack_kernel(int n, const float *linear, float exposure, un
 struct RadBuffers {
     float *col = nullptr, *nrm = nullptr;                      // [NP][3] clouds (engine.rs:274-281)
     float *emissive = nullptr, *emissive_next = nullptr;       // [NP][3]
-    float *ft = nullptr;                                       // [NP][NP] form factors
+    float *ft = nullptr;                                       // form factors, rad_ft_floats(NP) of them (blocks of 64 receivers, rad_ft_at)
 };
 
 struct RadArgs {
@@ -546,8 +546,17 @@ struct RadArgs {
     float *emissive;        // [NP][3] current emissive maps
     float *emissive_next;   // [NP][3]
     float *lightmaps;       // [NP][3]
-    float *ft;              // [NP][NP] form factors, ft[j * NP + i]: source j -> receiver i; -1 = no contribution
+    float *ft;              // form factors, source j -> receiver i at rad_ft_at(i, j, NP); -1 = no contribution
 };
+// The form-factor matrix lies in blocks of 64 receivers: block b holds its receivers' values for
+// source 0, then for source 1, ... (64 floats each), so the workgroup of a bounce, which folds every
+// source into 64 receivers, reads one unbroken run of memory, and the wave of a form-factor launch
+// (64 receivers, one source) writes one 256-byte piece of it.  ceil(NP / 64) * 64 * NP floats.
+__host__ __device__ __forceinline__ size_t rad_ft_at(int i, int j, int NP) { return ((size_t)(i >> 6) * NP + j) * 64 + (i & 63); }
+// (plus room for the deepest slab of a bounce to read past the last source of the last block: what
+// such a read brings is discarded, but it has to stay inside the allocation)
+constexpr size_t kRadFtPadFloats = 192 * 64;
+__host__ __device__ __forceinline__ size_t rad_ft_floats(int NP) { return (size_t)((NP + 63) / 64) * 64 * NP + kRadFtPadFloats; }
 
 // engine.rs:269-281: colour and normal of every sample point.
 __global__ void rad_cloud_kernel(const RadArgs a) {
@@ -659,7 +668,7 @@ __global__ void rad_form_kernel(const RadArgs a, int p0, int p1, int j0, int dir
         V3 sample_n = v3(a.nrm[3 * i], a.nrm[3 * i + 1], a.nrm[3 * i + 2]);
         f = rad_form_pair(a, grp, j, recv_obj, sample_pos, sample_n);
     }
-    a.ft[(size_t)j * a.n_patches + i] = f;
+    a.ft[rad_ft_at(i, j, a.n_patches)] = f;
 }
 // The same with `per` sources per workgroup, one after the other: what a wave sets up - the scene in
 // scalar registers, its receivers' points and normals - then serves several marches.  For launches
@@ -677,7 +686,7 @@ __global__ void rad_form_multi_kernel(const RadArgs a, int p0, int p1, int j0, i
     for (int j = jb; j < je; j++) {
         float f = -1.0f;
         if (i / mm != j / mm) f = rad_form_pair(a, grp, j, recv_obj, sample_pos, sample_n);  // radiosity.rs:112
-        a.ft[(size_t)j * a.n_patches + i] = f;
+        a.ft[rad_ft_at(i, j, a.n_patches)] = f;
     }
 }
 
@@ -722,12 +731,18 @@ __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0
     // memory one after the other.  What a clamped load brought is discarded when the slab is stored.
     // Thread (part, lane) fetches rows 4g .. 4g+3 for g = part, part + 4, ...: each load is a row
     // segment of 64 receivers, and the four values of a group leave for LDS in one 16-byte store.
+    // Rows past the last source are read where they would lie (the next block, or the padding behind
+    // the last one): one address per group, the four rows at fixed distances from it.
+    static_assert((size_t)CHUNK * 64 <= kRadFtPadFloats, "the padding behind the matrix covers a slab");
     const int ic = min(i, NP - 1);
+    const float *const column = a.ft + rad_ft_at(ic, 0, NP);
     const auto fetch = [&](int j0) {
 #pragma unroll
-        for (int k = 0; k < kGroups; k++)
+        for (int k = 0; k < kGroups; k++) {
+            const float *const g = column + (size_t)(j0 + 4 * (part + 4 * k)) * 64;
 #pragma unroll
-            for (int q = 0; q < 4; q++) pre[4 * k + q] = a.ft[(size_t)min(j0 + 4 * (part + 4 * k) + q, NP - 1) * NP + ic];
+            for (int q = 0; q < 4; q++) pre[4 * k + q] = g[q * 64];
+        }
 #pragma unroll
         for (int k = 0; k < kEmPerThread; k++) em_pre[k] = a.emissive[min(3 * j0 + (int)threadIdx.x + 256 * k, 3 * NP - 1)];
     };
@@ -955,12 +970,12 @@ __global__ __launch_bounds__(256) void unpack_bgr_strips_kernel(const unsigned *
 // ===========================================================================
 
 // Static scratch for rm_engine_compute_lightmaps_static: four [NP][3] float arrays (each rounded up
-// to 64 floats) and the [NP][NP] form-factor matrix for NP <= RM_STATIC_MAX_PATCHES.  Every GPU the
+// to 64 floats) and the form-factor matrix (rad_ft_floats(NP) floats) for NP <= RM_STATIC_MAX_PATCHES.  Every GPU the
 // library runs on holds its own copy (4.05 MiB) at its own address until the process ends.  In host
 // code the name below is only a handle for hipGetSymbolAddress: the address kernels and memsets are
 // given is the one static_scratch_of() returns for the current device.
 constexpr size_t kStaticCloudFloats = ((size_t)RM_STATIC_MAX_PATCHES * 3 + 63) & ~(size_t)63;
-constexpr size_t kStaticScratchFloats = 4 * kStaticCloudFloats + (size_t)RM_STATIC_MAX_PATCHES * RM_STATIC_MAX_PATCHES;
+constexpr size_t kStaticScratchFloats = 4 * kStaticCloudFloats + (size_t)RM_STATIC_MAX_PATCHES * RM_STATIC_MAX_PATCHES + kRadFtPadFloats;
 static __device__ __align__(256) float scratch[kStaticScratchFloats];
 
 constexpr int kMaxDevices = 64;
@@ -2497,7 +2512,7 @@ int rm_engine_radiosity_form_factors(rm_engine *e, int p0, int p1) {
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_ = sync_view(e)) return rc_;
     const int NP = e->n_patches;
-    if (!e->rad.ft) HIP_TRY(dev_alloc(&e->rad.ft, (size_t)NP * NP));
+    if (!e->rad.ft) HIP_TRY(dev_alloc(&e->rad.ft, rad_ft_floats(NP)));
     return rad_form_on(e, e->rad, p0, p1);
 }
 
@@ -2558,7 +2573,7 @@ int rm_engine_compute_lightmaps(rm_engine *e, int bounces) {
         HIP_TRY(dev_alloc(&e->rad.emissive, (size_t)NP * 3));
         HIP_TRY(dev_alloc(&e->rad.emissive_next, (size_t)NP * 3));
     }
-    if (bounces > 0 && !e->rad.ft) HIP_TRY(dev_alloc(&e->rad.ft, (size_t)NP * NP));
+    if (bounces > 0 && !e->rad.ft) HIP_TRY(dev_alloc(&e->rad.ft, rad_ft_floats(NP)));
     e->rad_begun = true;
     if (int rc = rad_whole_on(e, e->rad, bounces)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -2579,7 +2594,7 @@ int rm_engine_compute_lightmaps_static(rm_engine *e, int bounces) {
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_ = sync_view(e)) return rc_;
     if (int rc_ = quiesce_frames_in_flight(e)) return rc_;
-    // the scratch array, cut up for NP patches: four [NP][3] arrays, then FT [NP][NP] on a 256-byte boundary
+    // the scratch array, cut up for NP patches: four [NP][3] arrays, then FT (rad_ft_floats(NP) floats) on a 256-byte boundary
     const size_t cloud = ((size_t)NP * 3 + 63) & ~(size_t)63;
     RadBuffers b;
     b.col = e->scratch;
