@@ -43,6 +43,46 @@ def test_form_factor_launch_in_chunks(scene, oracle_lightmaps, monkeypatch):
     assert np.array_equal(got.view(np.uint32), lm[4].view(np.uint32))
 
 
+@pytest.mark.parametrize("per,chunk", [("3", "100"), ("16", None)])
+def test_form_factors_several_sources_per_workgroup(scene, oracle_lightmaps, monkeypatch, per, chunk):
+    """Large launches give a workgroup several sources, one after the other (rad_form_multi_kernel,
+    chosen by launch size); forced here on the default maps, with a count that does not divide a
+    launch's rows and with launches in chunks - the lightmaps equal the oracle's bit for bit."""
+    from raymarching_amd import Engine
+
+    lm, _ = oracle_lightmaps
+    monkeypatch.setenv("RM_RAD_PER", per)
+    if chunk:
+        monkeypatch.setenv("RM_RAD_CHUNK", chunk)
+    e = Engine(scene, 64, 64)
+    e.compute_lightmaps(4)
+    got = np.stack([e.get_lightmap(i) for i in range(e.n_objects)])
+    e.close()
+    assert np.array_equal(got.view(np.uint32), lm[4].view(np.uint32))
+
+
+def test_stepwise_calls_after_a_whole_precompute(scene, oracle_lightmaps):
+    """The one-call precompute lets the two emissive maps trade places from bounce to bounce; the
+    stepwise calls made on the same engine afterwards (odd and even bounce counts before them) still
+    deliver the oracle's lightmaps."""
+    from raymarching_amd import Engine
+
+    lm, _ = oracle_lightmaps
+    e = Engine(scene, 64, 64)
+    for before in (1, 4):
+        e.compute_lightmaps(before)
+        e.radiosity_begin()
+        _, _, n = e.radiosity_buffers()
+        e.radiosity_form_factors(0, n)
+        for _ in range(4):
+            e.radiosity_bounce(0, n)
+            e.radiosity_commit()
+        e.synchronize()
+        got = np.stack([e.get_lightmap(i) for i in range(e.n_objects)])
+        assert np.array_equal(got.view(np.uint32), lm[4].view(np.uint32)), before
+    e.close()
+
+
 def test_large_maps_run(scene):
     """MAP_SIZE 32 (8192 patches, 67 M form factors): finite, non-negative, and the same luxels
     empty as geometry dictates.  (The CPU oracle would need hours at this size.)"""
