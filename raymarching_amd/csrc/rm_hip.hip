@@ -1084,6 +1084,18 @@ struct rm_engine {
     hipStream_t plan_stream[8] = {};    // the stream each plan of the ring belongs to
     bool plan_taken[8] = {};
     unsigned char plan_parity[8] = {};  // which of a plan's two sets of count words its next launch uses
+    // a plan serves the launches that follow it on its stream while they name the same tiles (see launch_render)
+    struct PlanKey {
+        unsigned grid_x = 0, per = 0, cap = 0;
+        int row_begin = 0, row_end = 0, tile_row_stride = 0, blocks_x = 0, blocks_y = 0;
+        bool operator==(const PlanKey &o) const {
+            return grid_x == o.grid_x && per == o.per && cap == o.cap && row_begin == o.row_begin && row_end == o.row_end &&
+                   tile_row_stride == o.tile_row_stride && blocks_x == o.blocks_x && blocks_y == o.blocks_y;
+        }
+    } plan_key[8];
+    unsigned plan_launches[8] = {};       // launches the stream's plans have served since the first
+    unsigned *plan_count_word[8] = {};    // the count word of the plan in force
+    int plan_every = -1;                  // a fresh plan every so many launches (RM_PLAN_EVERY)
     int split_threshold = -1;           // ticks; 0 = off; -1 = not read yet (RM_SPLIT_US)
     bool split_on = true;               // rm_engine_set_tile_splitting
     unsigned dense_tiles = 0;           // launches of the small tiers from this many tiles on take the 8-wave build (0 = the default)
@@ -2061,8 +2073,6 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
             return RM_OK;
         }
         unsigned *const words = e->d_plan_words + (size_t)slot * kPlanStride, *list = words + 64;
-        unsigned *count = words + 16 * e->plan_parity[slot], *count_next = words + 16 * (e->plan_parity[slot] ^ 1);
-        e->plan_parity[slot] ^= 1;
         unsigned char *flag = e->d_plan_flags + (size_t)slot * frame_tiles;
         a.tile_cost = e->d_tile_cost;
         a.cost_tiles = (unsigned)frame_tiles;
@@ -2072,12 +2082,38 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         a.plan_per = long_launch ? 1u : 4u;
 #endif
         a.plan_cap = std::min<unsigned>(long_launch ? kPlanCapEarly : kPlanCap, std::max<unsigned>(16u, grid.x / 16u));
-        const unsigned *previous = e->last_plan_count ? e->last_plan_count : words + 32;  // (the first plan: words that stay zero)
-        hipLaunchKernelGGL(split_plan_kernel, dim3((grid.x + 255) / 256), dim3(256), 0, e->stream, a, count, list, flag,
-                           (unsigned)e->split_threshold, previous, long_launch ? e->early_times_mean : e->split_times_mean,
-                           count_next);
-        a.plan_count = count;
-        e->last_plan_count = count;
+        // A plan stays in force for the launches that follow it on its stream as long as they name the
+        // same tiles: list and flags are left as they are, so every pixel is still rendered exactly once,
+        // and a plan that has aged costs time at worst, like any wrong guess.  A fresh one is made for a
+        // stream's first two launches (the first has no lifetimes to go by) and every eighth after that -
+        // the plan kernel is 5 us in front of a launch that may take 100.
+        if (e->plan_every < 0) {
+            const char *v = getenv("RM_PLAN_EVERY");  // (1: a fresh plan for every launch)
+            e->plan_every = v ? std::max(1, std::min(atoi(v), 1 << 20)) : 8;
+        }
+        rm_engine::PlanKey key;
+        key.grid_x = grid.x;
+        key.per = a.plan_per;
+        key.cap = a.plan_cap;
+        key.row_begin = a.row_begin;
+        key.row_end = a.row_end;
+        key.tile_row_stride = a.tile_row_stride;
+        key.blocks_x = a.blocks_x;
+        key.blocks_y = a.blocks_y;
+        const unsigned served = e->plan_launches[slot]++;
+        const bool fresh = served < 2 || served % (unsigned)e->plan_every == 0 || !(key == e->plan_key[slot]);
+        if (fresh) {
+            unsigned *count = words + 16 * e->plan_parity[slot], *count_next = words + 16 * (e->plan_parity[slot] ^ 1);
+            e->plan_parity[slot] ^= 1;
+            const unsigned *previous = e->last_plan_count ? e->last_plan_count : words + 32;  // (the first plan: words that stay zero)
+            hipLaunchKernelGGL(split_plan_kernel, dim3((grid.x + 255) / 256), dim3(256), 0, e->stream, a, count, list, flag,
+                               (unsigned)e->split_threshold, previous, long_launch ? e->early_times_mean : e->split_times_mean,
+                               count_next);
+            e->plan_key[slot] = key;
+            e->plan_count_word[slot] = count;
+        }
+        a.plan_count = e->plan_count_word[slot];
+        e->last_plan_count = a.plan_count;
         e->last_plan_cap = a.plan_cap;
         a.plan_list = list;
         a.plan_flag = flag;
