@@ -2085,8 +2085,9 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         // A plan stays in force for the launches that follow it on its stream as long as they name the
         // same tiles: list and flags are left as they are, so every pixel is still rendered exactly once,
         // and a plan that has aged costs time at worst, like any wrong guess.  A fresh one is made for a
-        // stream's first two launches (the first has no lifetimes to go by) and every eighth after that -
-        // the plan kernel is 5 us in front of a launch that may take 100.
+        // stream's first four launches (the first has no lifetimes to go by, the second no mean to hold
+        // them against: a scene full of slow tiles overflows its list) and every eighth after that - the
+        // plan kernel is 5 us in front of a launch that may take 100.
         if (e->plan_every < 0) {
             const char *v = getenv("RM_PLAN_EVERY");  // (1: a fresh plan for every launch)
             e->plan_every = v ? std::max(1, std::min(atoi(v), 1 << 20)) : 8;
@@ -2101,7 +2102,10 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         key.blocks_x = a.blocks_x;
         key.blocks_y = a.blocks_y;
         const unsigned served = e->plan_launches[slot]++;
-        const bool fresh = served < 2 || served % (unsigned)e->plan_every == 0 || !(key == e->plan_key[slot]);
+        // (a long launch always gets a fresh plan: 5 us are nothing to it, and a plan made from the lifetimes
+        // of the frame before serves it better than an older one - the 7680x4320 stress frame takes 13.6 ms
+        // with fresh plans and 15.0 ms with one kept for eight frames)
+        const bool fresh = long_launch || served < 4 || served % (unsigned)e->plan_every == 0 || !(key == e->plan_key[slot]);
         if (fresh) {
             unsigned *count = words + 16 * e->plan_parity[slot], *count_next = words + 16 * (e->plan_parity[slot] ^ 1);
             e->plan_parity[slot] ^= 1;

@@ -33,7 +33,7 @@ for e, b in zip(engines, bufs):
     e.render_rows_device(b.data_ptr(), 0, H)
     e.synchronize()
 times = [[] for _ in engines]
-for r in range(5):
+for r in range(int(os.environ.get("RM_ROUNDS", 5))):
     for i, (e, b) in enumerate(zip(engines, bufs)):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
