@@ -35,7 +35,9 @@ for i, b in enumerate(bufs[1:], 1):
     print(f"{libs[i]}: image {'identical to' if same else 'DIFFERS from'} {libs[0]}")
 times = [[] for _ in engines]
 for r in range(ROUNDS):
-    for i, (e, b) in enumerate(zip(engines, bufs)):
+    # (the build that goes first after a pause measures up to 3 % slower: the rounds start with each in turn)
+    for i in [(r + k) % len(engines) for k in range(len(engines))]:
+        e, b = engines[i], bufs[i]
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(FRAMES):
