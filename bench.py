@@ -186,6 +186,69 @@ def radiosity_cpu_baseline(scene, budget_s):
     }
 
 
+def make_group(eng, rank, world, local_rank, backend, in_flight):
+    """The rank's rm_group over `eng`: RCCL inside the library where a communicator can be built on every
+    rank, else (a rehearsal with every rank on one GPU, or RCCL missing) the library's custom-exchange
+    form with an all-gather through host memory and gloo.  Returns (group, backend label)."""
+    import torch
+    import torch.distributed as dist
+
+    group = None
+    from raymarching_amd.group import Group, unique_id
+
+    if backend == "nccl":
+        # the 128-byte id is the only thing the ranks exchange outside the library
+        failure = None
+        try:
+            ids = [unique_id() if rank == 0 else None]
+        except Exception as exc:  # (no RCCL to be found: every rank must still reach the broadcast)
+            ids, failure = [None], f"{type(exc).__name__}: {exc}"
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        if ids[0] is None:
+            failure = failure or "rank 0 could not make a communicator id"
+        else:
+            try:
+                if os.environ.get("RM_BENCH_FAIL_RCCL") == "1":  # rehearsal of the fallback below
+                    raise RuntimeError("failure requested by RM_BENCH_FAIL_RCCL")
+                group = Group(eng, rank, world, ids[0], frames_in_flight=in_flight)
+            except Exception as exc:
+                failure = f"{type(exc).__name__}: {exc}"
+        # The transport is the ranks' common choice: if the communicator could not be built on any
+        # rank, all of them hand the library the host all-gather below instead (same frames, a
+        # slower exchange), and the line says so.  The rendering is the library's either way.
+        failures = [None] * world
+        if world > 1:
+            dist.all_gather_object(failures, failure)
+        else:
+            failures = [failure]
+        if any(failures):
+            if group is not None:
+                group.close()
+                group = None
+            backend = "gloo (RCCL communicator failed: " + next(f for f in failures if f)[:200] + ")"
+            print(f"[bench] rank {rank}: {backend}", file=sys.stderr)
+    if group is None:
+        # rehearsal on one GPU: RCCL refuses two ranks on one device, so the all-gather goes
+        # through host memory and gloo; everything else is the path above
+        def host_all_gather(d_send, d_recv, nbytes, hip_stream):
+            from raymarching_amd.dist import _alias_u8
+
+            torch.cuda.synchronize()
+            mine = _alias_u8(d_send, nbytes, local_rank).cpu()
+            if world > 1:
+                everyone = torch.empty(nbytes * world, dtype=torch.uint8)
+                dist.all_gather_into_tensor(everyone, mine)
+            else:
+                everyone = mine
+            _alias_u8(d_recv, nbytes * world, local_rank).copy_(everyone)
+            torch.cuda.synchronize()
+            return 0
+
+        group = Group(eng, rank, world, frames_in_flight=in_flight, all_gather=host_all_gather)
+    return group, backend
+
+
 def radiosity_workload(args, world, rank, local_rank, backend):
     """One step = Engine::compute_lightmaps (engine.rs:246-326): clouds, direct lighting, the
     form-factor matrix of all patch pairs, 4 bounces; receiver patches sharded over the ranks with
@@ -201,12 +264,7 @@ def radiosity_workload(args, world, rank, local_rank, backend):
     gathering = world > 1 or os.environ.get("RM_BENCH_GATHER_ALONE") == "1"
     group = None
     if gathering:
-        from raymarching_amd.group import Group, unique_id
-
-        ids = [unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(ids, src=0)
-        group = Group(eng, rank, world, ids[0], frames_in_flight=1)
+        group, backend = make_group(eng, rank, world, local_rank, backend, 1)
     steps, warmup = min(args.steps, 20), min(args.warmup, 3)
     n = 8 * M * M
     phase_ms = {"form_factors": 0.0, "bounces": 0.0}
@@ -383,58 +441,7 @@ def main():
     n_buf = max(in_flight, 2)
     group = None
     if gathering:
-        from raymarching_amd.group import Group, unique_id
-
-        if backend == "nccl":
-            # the 128-byte id is the only thing the ranks exchange outside the library
-            failure = None
-            try:
-                ids = [unique_id() if rank == 0 else None]
-            except Exception as exc:  # (no RCCL to be found: every rank must still reach the broadcast)
-                ids, failure = [None], f"{type(exc).__name__}: {exc}"
-            if world > 1:
-                dist.broadcast_object_list(ids, src=0)
-            if ids[0] is None:
-                failure = failure or "rank 0 could not make a communicator id"
-            else:
-                try:
-                    if os.environ.get("RM_BENCH_FAIL_RCCL") == "1":  # rehearsal of the fallback below
-                        raise RuntimeError("failure requested by RM_BENCH_FAIL_RCCL")
-                    group = Group(eng, rank, world, ids[0], frames_in_flight=in_flight)
-                except Exception as exc:
-                    failure = f"{type(exc).__name__}: {exc}"
-            # The transport is the ranks' common choice: if the communicator could not be built on any
-            # rank, all of them hand the library the host all-gather below instead (same frames, a
-            # slower exchange), and the line says so.  The rendering is the library's either way.
-            failures = [None] * world
-            if world > 1:
-                dist.all_gather_object(failures, failure)
-            else:
-                failures = [failure]
-            if any(failures):
-                if group is not None:
-                    group.close()
-                    group = None
-                backend = "gloo (RCCL communicator failed: " + next(f for f in failures if f)[:200] + ")"
-                print(f"[bench] rank {rank}: {backend}", file=sys.stderr)
-        if group is None:
-            # rehearsal on one GPU: RCCL refuses two ranks on one device, so the all-gather goes
-            # through host memory and gloo; everything else is the path above
-            def host_all_gather(d_send, d_recv, nbytes, hip_stream):
-                from raymarching_amd.dist import _alias_u8
-
-                torch.cuda.synchronize()
-                mine = _alias_u8(d_send, nbytes, local_rank).cpu()
-                if world > 1:
-                    everyone = torch.empty(nbytes * world, dtype=torch.uint8)
-                    dist.all_gather_into_tensor(everyone, mine)
-                else:
-                    everyone = mine
-                _alias_u8(d_recv, nbytes * world, local_rank).copy_(everyone)
-                torch.cuda.synchronize()
-                return 0
-
-            group = Group(eng, rank, world, frames_in_flight=in_flight, all_gather=host_all_gather)
+        group, backend = make_group(eng, rank, world, local_rank, backend, in_flight)
         group.compute_lightmaps(4)  # the same precompute, patch-sharded (a rehearsal of that exchange too)
         info = group.info()
         strips_per_rank, wire = info["strips_per_rank"], info["bytes_per_pixel_exchanged"]
