@@ -214,19 +214,24 @@ static void group_patch_range(const rm_group *g, int &p0, int &p1) {
     p1 = std::min(p0 + g->per_patches, g->e->n_patches);
 }
 
-// All-gathers the ranks' slices [p0, p1) of the [n_patches][3] array `d_values` into all of it.
-static int group_gather_patches(rm_group *g, float *d_values) {
+// All-gathers the ranks' slices [p0, p1) of the [n_patches][3] array `d_src` into the whole of `d_dst`
+// (the same array, or another of the same shape).
+static int group_gather_patches(rm_group *g, const float *d_src, float *d_dst) {
     rm_engine *e = g->e;
     int p0, p1;
     group_patch_range(g, p0, p1);
     const size_t per = (size_t)g->per_patches * 3;
     if (per == 0) return RM_OK;
-    // slices are equal parts on the wire; the tail of the last ranks' is padding
+    // Equal slices that end up in another array travel as they lie: from this rank's part of the source
+    // straight into the destination, no staging copies.
+    if ((size_t)g->per_patches * g->world == (size_t)e->n_patches && d_src != d_dst)
+        return group_all_gather(g, d_src + (size_t)p0 * 3, d_dst, per, true, e->stream);
+    // otherwise slices are equal parts on the wire; the tail of the last ranks' is padding
     HIP_TRY(hipMemsetAsync(g->d_slice, 0, per * sizeof(float), e->stream));
     if (p1 > p0)
-        HIP_TRY(hipMemcpyAsync(g->d_slice, d_values + (size_t)p0 * 3, (size_t)(p1 - p0) * 3 * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(g->d_slice, d_src + (size_t)p0 * 3, (size_t)(p1 - p0) * 3 * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
     if (int rc = group_all_gather(g, g->d_slice, g->d_whole, per, true, e->stream)) return rc;
-    HIP_TRY(hipMemcpyAsync(d_values, g->d_whole, (size_t)e->n_patches * 3 * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d_dst, g->d_whole, (size_t)e->n_patches * 3 * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
     return RM_OK;
 }
 
@@ -393,13 +398,13 @@ int rm_group_compute_lightmaps(rm_group *g, int bounces) {
     for (int b = 0; b < bounces; b++) {
         rc = rm_engine_radiosity_bounce(e, p0, p1);
         if (rc) return rc;
-        rc = group_gather_patches(g, e->rad.emissive_next);
-        if (rc) return rc;
-        rc = rm_engine_radiosity_commit(e);
+        // the gathered slices are the next bounce's emissive map: they land in it directly
+        // (rm_engine_radiosity_commit, the copy from the one map to the other, has nothing left to do)
+        rc = group_gather_patches(g, e->rad.emissive_next, e->rad.emissive);
         if (rc) return rc;
     }
     if (bounces > 0) {
-        rc = group_gather_patches(g, e->d_lightmaps);
+        rc = group_gather_patches(g, e->d_lightmaps, e->d_lightmaps);
         if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
