@@ -47,6 +47,13 @@ def parse_args():
                     help="render: the headline frame benchmark; radiosity: Engine::compute_lightmaps, patch-sharded; "
                     "stress: 256 mixed primitives with smooth unions at 7680x4320, march cap 1024")
     ap.add_argument("--map-size", type=int, default=8, help="lightmap edge for --workload radiosity (8 in the reference)")
+    ap.add_argument("--exchange", choices=["all_gather", "presenter"], default="all_gather",
+                    help="several GPUs: where a frame ends up in the timed region - on every rank (one all-gather per frame, the "
+                         "default) or on rank f mod N alone (the strips gathered to a rotating presenter); the other one is "
+                         "measured after the timed region and reported beside it")
+    ap.add_argument("--preroll-seconds", type=float, default=0.3,
+                    help="untimed frames rendered before --warmup so that the timed region does not sit on the clock ramp")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements after the timed region")
     return ap.parse_args()
 
 
@@ -245,7 +252,23 @@ def make_group(eng, rank, world, local_rank, backend, in_flight):
             torch.cuda.synchronize()
             return 0
 
-        group = Group(eng, rank, world, frames_in_flight=in_flight, all_gather=host_all_gather)
+        def host_gather(d_send, d_recv, nbytes, root, hip_stream):
+            from raymarching_amd.dist import _alias_u8
+
+            torch.cuda.synchronize()
+            mine = _alias_u8(d_send, nbytes, local_rank).cpu()
+            if world > 1:
+                parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)] if rank == root else None
+                dist.gather(mine, parts, dst=root)
+                everyone = torch.cat(parts) if rank == root else None
+            else:
+                everyone = mine
+            if rank == root:
+                _alias_u8(d_recv, nbytes * world, local_rank).copy_(everyone)
+            torch.cuda.synchronize()
+            return 0
+
+        group = Group(eng, rank, world, frames_in_flight=in_flight, all_gather=host_all_gather, gather=host_gather)
     return group, backend
 
 
@@ -504,34 +527,190 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup, False)
-    fence()
-    t0 = time.perf_counter()
-    run(args.steps, True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region(steps):
+        """`steps` frames between two fences; the maximum over the ranks' wall times, in seconds."""
+        fence()
+        t0 = time.perf_counter()
+        run(steps, True)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
+    if gathering and args.exchange == "presenter":
+        group.set_exchange("presenter")
+    # Pre-roll (untimed set-up, like the precompute): a GPU that has idled starts below the clock it
+    # settles at under load; a timed region of a few milliseconds would sit on that ramp.  Every rank
+    # runs the same number of frames (the group's frames are collective).
+    preroll_frames = 0
+    if args.preroll_seconds > 0:
+        t_pre = time.perf_counter()
+        run(8, False)
+        torch.cuda.synchronize()
+        per8 = max(time.perf_counter() - t_pre, 1e-4)
+        rounds = int(min(max(args.preroll_seconds / per8, 1.0), 400.0))
+        if world > 1:
+            t = torch.tensor([rounds], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            rounds = int(t.item())
+        for _ in range(rounds):
+            run(8, False)
+        torch.cuda.synchronize()
+        preroll_frames = 8 * (rounds + 1)
+    run(args.warmup, False)
+    elapsed = timed_region(args.steps)
+
+    exchange_ms = None
     if gathering:
-        kernel_ms, _ = group.render_time()  # events around the render launch on each frame's own stream
+        kernel_ms, _ = group.render_time()  # events around the render launch on each frame's own stream (spans overlap with frames in flight)
+        exchange_ms_overlapped, _ = group.exchange_time()
+        per_frame_kernel = []
     else:
-        kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
+        per_frame_kernel = [a.elapsed_time(b) for a, b in kernel_events]
+        kernel_ms = sum(per_frame_kernel) / max(len(per_frame_kernel), 1)
     stats = eng.stats()
+    last_buf = (args.steps - 1) % n_buf if gathering or in_flight > 1 else (args.steps - 1) & 1  # where the last frame landed
+    # (the presenter rotates with every frame the group has issued in this mode, pre-roll and warm-up included)
+    last_presenter = (group.next_presenter() - 1) % world if gathering and args.exchange == "presenter" else None
+
+    # ---- secondary measurements, after the timed region (none of them is `value`) ----
+    extras = {}
+    whole = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    whole_fx = torch.zeros_like(whole) if args.fxaa else None
+
+    def render_local():
+        eng.render_rows_device(whole.data_ptr(), 0, H)
+        if args.fxaa:
+            eng.fxaa_device(whole.data_ptr(), whole_fx.data_ptr(), 0, H)
+
+    checks = {}
+    if gathering:
+        # the gathered frame against the same frame rendered (and filtered) whole on this GPU, bit for bit
+        render_local()
+        torch.cuda.synchronize()
+        local = whole_fx if args.fxaa else whole
+        if last_presenter is None or last_presenter == rank:
+            checks[args.exchange] = bool(torch.equal(final[last_buf], local))
+    if gathering and not args.no_extras:
+        calib = 16
+        # (a) this rank's share rendered alone and the collective alone: one frame at a time, nothing else on the GPU
+        group.set_exchange("all_gather")
+        group.set_timing(True)
+        for s in range(calib):
+            group.frame(final[s % n_buf].data_ptr(), args.fxaa)
+            group.wait()
+        share_ms, _ = group.render_time()
+        ag_ms, _ = group.exchange_time()
+        group.set_exchange("presenter")
+        group.set_timing(True)
+        for s in range(calib):
+            group.frame(final[s % n_buf].data_ptr(), args.fxaa)
+            group.wait()
+        pr_ms, _ = group.exchange_time()
+        group.set_timing(False)
+        kernel_alone_ms = share_ms
+        # (b) the whole frame on this rank alone, every rank at the same time: what one GPU does without the group
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(calib):
+            render_local()
+        torch.cuda.synchronize()
+        n1_ms = (time.perf_counter() - t0) / calib * 1e3
+        # (c) the other exchange, timed like the headline
+        other = "presenter" if args.exchange == "all_gather" else "all_gather"
+        group.set_exchange(other)
+        run(args.warmup, False)
+        other_elapsed = timed_region(args.steps)
+        other_last = (args.steps - 1) % n_buf
+        if other == "all_gather" or (group.next_presenter() - 1) % world == rank:
+            checks[other] = bool(torch.equal(final[other_last], local))
+        if world > 1:
+            t = torch.tensor([share_ms, ag_ms, pr_ms, n1_ms], dtype=torch.float64)
+            tmax, tmean = t.clone(), t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tmean, op=dist.ReduceOp.SUM)
+            tmean /= world
+            gathered_checks = [None] * world
+            dist.all_gather_object(gathered_checks, checks)
+            checks = {k: all(c[k] for c in gathered_checks if k in c) for k in ("all_gather", "presenter") if any(k in c for c in gathered_checks)}
+        else:
+            tmax = tmean = torch.tensor([share_ms, ag_ms, pr_ms, n1_ms], dtype=torch.float64)
+        ms_per_step = elapsed / args.steps * 1e3
+        other_ms = other_elapsed / args.steps * 1e3
+        extras = {
+            "render_share_ms": {"mean": float(tmean[0]), "max_over_ranks": float(tmax[0]),
+                                "note": "this rank's strips rendered alone (one frame at a time, events around the launch)"},
+            "exchange_ms": {"all_gather": {"mean": float(tmean[1]), "max_over_ranks": float(tmax[1])},
+                            "presenter_gather": {"mean": float(tmean[2]), "max_over_ranks": float(tmax[2])},
+                            "note": "the collective alone, one frame at a time (events around it on the frame's stream)"},
+            "n1_ms_per_frame": {"mean": float(tmean[3]), "max_over_ranks": float(tmax[3]),
+                                "note": "the whole frame on one rank's GPU without the group, every rank at the same time"},
+            "efficiency_vs_n1": float(tmean[3]) / (world * ms_per_step),
+            "other_exchange": {"exchange": other, "ms_per_step": other_ms, "value": W * H * (4 if args.ssaa else 1) / (other_ms * 1e-3) / 1e6,
+                               "unit": "Mrays/s", "efficiency_vs_n1": float(tmean[3]) / (world * other_ms), "steps": args.steps,
+                               "note": "the same frames through the other exchange, timed like the headline"},
+            "communicators": group.communicators(),
+        }
+        exchange_ms = extras["exchange_ms"]
+    elif not gathering and not args.no_extras and args.workload == "render" and not args.ssaa and not args.refraction:
+        # the shader clock under this load: the probe wave runs beside frames that are enqueued first
+        run(60 if W * H <= 1920 * 1080 else 30, False)
+        clock_load = eng.shader_clock_mhz(200)
+        torch.cuda.synchronize()
+        eng.set_stream(stream.cuda_stream)
+        # the reference-shaped call: Engine::render into host memory (main.rs:141-145), PCIe included
+        from raymarching_amd import _lib as rm_lib
+        import ctypes
+
+        lib = rm_lib.load()
+        n_abi = 8
+        pinned = lib.rm_host_alloc(W * H * 4)
+        abi = {}
+        if pinned:
+            ptr = ctypes.cast(ctypes.c_void_p(pinned), ctypes.POINTER(ctypes.c_uint8))
+            zero = rm_lib.f3((0.0, 0.0, 0.0))
+            for _ in range(2):
+                rm_lib.check(lib.rm_engine_render(eng.handle, ptr, W * 4, 0, 0, zero, 0), "rm_engine_render")
+            t0 = time.perf_counter()
+            for _ in range(n_abi):
+                rm_lib.check(lib.rm_engine_render(eng.handle, ptr, W * 4, 0, 0, zero, 0), "rm_engine_render")
+            abi["page_locked_ms"] = (time.perf_counter() - t0) / n_abi * 1e3
+            lib.rm_host_free(pinned)
+        pageable = np.empty((H, W, 4), dtype=np.uint8)
+        for _ in range(2):
+            eng.render(pageable)
+        t0 = time.perf_counter()
+        for _ in range(n_abi):
+            eng.render(pageable)
+        abi["pageable_ms"] = (time.perf_counter() - t0) / n_abi * 1e3
+        abi["frames"] = n_abi
+        abi["note"] = "rm_engine_render: input block, frame, copy into the caller's host buffer (PCIe-inclusive; never `value`)"
+        for k in ("page_locked_ms", "pageable_ms"):
+            if k in abi:
+                abi[k.replace("_ms", "_mrays_per_s")] = W * H / (abi[k] * 1e-3) / 1e6
+        extras = {"shader_clock_mhz": {"under_load": clock_load, "nominal": 2400.0,
+                                       "note": "one wave counting shader cycles over 200 us of the constant-rate counter while frames render"},
+                  "abi_render": abi}
 
     result = None
-    last_buf = (args.steps - 1) % n_buf if gathering or in_flight > 1 else (args.steps - 1) & 1  # where the last frame landed
     if rank == 0:
         rays = W * H * (4 if args.ssaa else 1)
         ms_per_step = elapsed / args.steps * 1e3
         counters = load_counters(W, H) if args.workload == "render" and not args.ssaa and not args.refraction else None
         roofline = None
-        if counters is not None:
+        roof_kernel_ms = kernel_ms
+        if gathering:
+            # with frames in flight the events around one launch span other launches too: the roofline is
+            # that of this rank's share rendered alone, or nothing
+            roof_kernel_ms = extras["render_share_ms"]["mean"] if extras else None
+        if counters is not None and roof_kernel_ms:
             band_share = (r1 - r0) / H  # flops are counted for the whole frame; a band is its share by rows
             flops = frame_flops(counters)
-            achieved = flops * band_share / (kernel_ms * 1e-3) / 1e12
+            achieved = flops * band_share / (roof_kernel_ms * 1e-3) / 1e12
+            tiles = ((W + 7) // 8) * ((r1 - r0 + 7) // 8)
             roofline = {
                 "bound": "valu",
                 "achieved": achieved,
@@ -542,14 +721,29 @@ def main():
                 "traffic": int(measured_traffic(W, H) * band_share) if measured_traffic(W, H) else None,
                 "traffic_source": "rocprofv3 PMC passes committed under profiles/ (not collected live)",
                 # (a launch of 65536 tiles or more of a small scene runs the build of the kernel for 8 waves per SIMD)
-                "kernel": "render_dense_kernel" if ((W + 7) // 8) * ((r1 - r0 + 7) // 8) >= 65536 and not args.ssaa and not args.refraction else "render_kernel",
-                "kernel_ms": kernel_ms,
+                "kernel": "render_dense_kernel" if tiles >= 65536 and not args.ssaa and not args.refraction else "render_kernel",
+                "kernel_ms": roof_kernel_ms,
                 # a launch of fewer than 65536 tiles with one frame in flight is planned (slow tiles first and in
                 # quarters): the events then also span the plan's 5 us kernel
-                "kernel_ms_spans_the_launch_plan": bool(((W + 7) // 8) * ((r1 - r0 + 7) // 8) < 65536 and in_flight == 1 and not args.ssaa and not args.refraction and not gathering),
+                "kernel_ms_spans_the_launch_plan": bool(tiles < 65536 and (in_flight == 1 or gathering) and not args.ssaa and not args.refraction),
                 "algorithmic_flops_per_launch": int(flops * band_share),
                 "note": "FP32 vector ALU bound (no MFMA, HBM traffic is 4 B per ray); strict IEEE parity forbids FMA contraction",
             }
+            if per_frame_kernel:
+                srt = sorted(per_frame_kernel)
+                roofline["kernel_ms_min"] = srt[0]
+                roofline["kernel_ms_median"] = srt[len(srt) // 2]
+                roofline["kernel_ms_max"] = srt[-1]
+                k = max(1, min(5, len(per_frame_kernel) // 2))
+                roofline["kernel_ms_first_frames"] = sum(per_frame_kernel[:k]) / k
+                roofline["kernel_ms_last_frames"] = sum(per_frame_kernel[-k:]) / k
+                roofline["first_frames_slower_than_last"] = bool(roofline["kernel_ms_first_frames"] > 1.03 * roofline["kernel_ms_last_frames"])
+            if gathering:
+                roofline["kernel_ms_source"] = "calibration after the timed region: one frame at a time, nothing else on the GPU"
+            clock = extras.get("shader_clock_mhz", {}).get("under_load") if extras else None
+            if clock:
+                roofline["shader_clock_mhz"] = clock
+                roofline["frac_of_peak_at_measured_clock"] = achieved / (PEAK_FP32_TFLOPS * clock / 2400.0)
         result = {
             "metric": "primary Mrays/s at 4K" if (W, H) == (3840, 2160) and args.workload == "render" else f"primary Mrays/s at {W}x{H}",
             "value": rays / (elapsed / args.steps) / 1e6,
@@ -574,30 +768,29 @@ def main():
                 "height": H,
                 "bands": world,
                 "sharding": "interleaved 8-row strips" if gathering else "none",
-                "exchange": ("one all-gather per frame inside the library (rm_group_frame), " + ("RCCL" if backend == "nccl" else ("gloo through host memory (rehearsal)" if backend == "gloo" else backend))) if gathering else None,
+                "exchange": (("one all-gather per frame inside the library (rm_group_frame), " if args.exchange == "all_gather" else
+                              "strips gathered to a rotating presenter (frame f lands on rank f mod N) inside the library (rm_group_frame), ")
+                             + ("RCCL" if backend == "nccl" else ("gloo through host memory (rehearsal)" if backend == "gloo" else backend))) if gathering else None,
                 "fxaa_after_gather": bool(args.fxaa and gathering),
                 "fxaa": bool(args.fxaa),
                 "ssaa": 4 if args.ssaa else 1,
                 "refraction": bool(args.refraction),
                 "map_size": 8,
                 "overlap_gather": gathering and not args.no_overlap,
-                "bytes_per_pixel_exchanged": wire if gathering else None,
+                "bytes_per_pixel_exchanged": (wire if args.exchange == "all_gather" else 4) if gathering else None,
                 "frames_in_flight": in_flight,
+                "preroll_frames": preroll_frames,
             },
             "roofline": roofline if args.workload == "render" else stress_roofline(W, H, kernel_ms),
             "cap_hits": stats,
         }
         if gathering:
-            # the gathered frame against the same frame rendered (and filtered) whole on this GPU, bit for bit
-            gathered = final[last_buf]
-            local = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
-            eng.render_rows_device(local.data_ptr(), 0, H)
-            if args.fxaa:
-                filtered = torch.zeros_like(local)
-                eng.fxaa_device(local.data_ptr(), filtered.data_ptr(), 0, H)
-                local = filtered
-            torch.cuda.synchronize()
-            result["gathered_frame_equals_single_gpu_render"] = bool(torch.equal(gathered, local))
+            result["gathered_frame_equals_single_gpu_render"] = bool(checks) and all(checks.values())
+            result["frame_checks"] = checks
+            result["kernel_ms_overlapped"] = kernel_ms
+            result["exchange_ms_overlapped"] = exchange_ms_overlapped
+        for k, v in extras.items():
+            result[k] = v
         if not args.no_cpu_baseline and not gathering:  # the CPU leg runs at N=1 only
             lightmaps = [eng.get_lightmap(i) for i in range(eng.n_objects)]
             base, cpu_rows = cpu_baseline(scene, lightmaps, W, H, args.cpu_seconds, args.ssaa, args.refraction)

@@ -162,8 +162,9 @@ int rm_engine_radiosity_buffers(rm_engine *engine, void **d_next_emissive, void 
  * form-factor matrix live in a static device array of the library (4.10 MiB per GPU, held until the
  * process ends) instead of buffers allocated on first use, and the call allocates nothing.
  * Limit: map_size^2 * lightmapped objects <= RM_STATIC_MAX_PATCHES, else RM_ERR_LIMIT.  Every engine
- * on one GPU shares that GPU's array: calls that overlap on one GPU race (calls on different GPUs do
- * not).  The stepwise rm_engine_radiosity_* entry points keep using the engine's own buffers. */
+ * on one GPU shares that GPU's array: calls from several engines or threads on one GPU take turns
+ * (a lock per GPU, held for the length of the call; calls on different GPUs run side by side).  The
+ * stepwise rm_engine_radiosity_* entry points keep using the engine's own buffers. */
 #define RM_STATIC_MAX_PATCHES 1024
 int rm_engine_compute_lightmaps_static(rm_engine *engine, int bounces);
 
@@ -302,6 +303,13 @@ int rm_engine_split_tiles(rm_engine *engine, uint32_t *count);
 int rm_engine_get_stats(rm_engine *engine, uint64_t stats[RM_STAT_COUNT]);
 int rm_engine_reset_stats(rm_engine *engine);
 
+/* Measurement aid (no counterpart in the reference): the clock the GPU's vector units run at right now,
+ * in MHz.  One wave on a stream of its own counts shader-clock cycles over `microseconds` of the
+ * constant-rate counter - beside whatever the engine's streams are running, so a caller that has
+ * frames enqueued gets the clock under that load (the nominal peak assumes 2400 MHz; a chip that is
+ * busy runs below it).  Returns when the wave has finished. */
+int rm_engine_shader_clock(rm_engine *engine, int microseconds, double *mhz);
+
 /* Block until everything enqueued on the engine's stream has finished. */
 int rm_engine_synchronize(rm_engine *engine);
 
@@ -355,10 +363,41 @@ int rm_group_frame(rm_group *group, void *d_bgra_frame, int fxaa, int32_t mouse_
 /* Blocks until every frame enqueued so far has landed in its buffer. */
 int rm_group_wait(rm_group *group);
 
-/* Measurement aid: with on != 0 every frame's render launch is bracketed by events on its stream;
- * rm_group_render_time waits for the frames and returns the mean over the (up to 256) last ones. */
+/* Where a frame of the group ends up.  The reference has exactly one consumer of a frame - the window
+ * texture its main loop locks (main.rs:141-145) - so nothing requires every rank to hold every frame:
+ *   RM_EXCHANGE_ALL_GATHER (default)  every rank receives every frame (3 bytes per pixel on the links);
+ *   RM_EXCHANGE_PRESENTER             frame f of the group lands on rank f mod world alone (the
+ *                                     "presenter" of that frame, rotating so that every rank's links and
+ *                                     post-passes carry one frame in `world`): the other ranks only send
+ *                                     their strips (4 bytes per pixel as rendered, no packing pass) and
+ *                                     run neither the re-ordering nor FXAA for it.
+ * Collective in the sense that every rank must select the same mode before the same frame; the frame
+ * count restarts at 0.  rm_group_next_presenter tells where the next rm_group_frame will leave its
+ * frame (-1: on every rank); on the other ranks rm_group_frame ignores `d_bgra_frame` (NULL allowed). */
+#define RM_EXCHANGE_ALL_GATHER 0
+#define RM_EXCHANGE_PRESENTER 1
+int rm_group_set_exchange(rm_group *group, int mode);
+int rm_group_next_presenter(const rm_group *group, int *rank);
+/* The gather-to-one-rank counterpart of rm_allgather_fn for groups made by rm_group_create_custom:
+ * on rank `root` the `bytes_per_rank` bytes at `d_send` of rank 0, 1, ... must land one after the
+ * other in `d_recv` (NULL on the other ranks), ordered on `hip_stream` or complete on return.  Without
+ * one, RM_EXCHANGE_PRESENTER runs the group's all-gather function and lets the other ranks drop what
+ * they receive. */
+typedef int (*rm_gather_fn)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank, int root, void *hip_stream);
+int rm_group_set_custom_gather(rm_group *group, rm_gather_fn gather, void *user);
+/* RCCL communicators the group's frames travel through: one per frame in flight (split from the
+ * group's own, so that the exchanges of consecutive frames are not chained through one communicator's
+ * launch order), 1 where RCCL cannot split or RM_GROUP_SHARED_COMM=1 is set, 0 for a custom exchange. */
+int rm_group_communicators(const rm_group *group, int *count);
+
+/* Measurement aid: with on != 0 every frame's render launch and its exchange (the collective alone,
+ * without packing and re-ordering) are bracketed by events on the frame's stream; rm_group_render_time
+ * and rm_group_exchange_time wait for the frames and return the mean over the (up to 256) last ones.
+ * With several frames in flight such a span also covers whatever else the GPU ran meanwhile: time a
+ * kernel alone with one frame in flight, or with rm_group_wait between frames. */
 int rm_group_set_timing(rm_group *group, int on);
 int rm_group_render_time(rm_group *group, double *mean_ms, int *frames);
+int rm_group_exchange_time(rm_group *group, double *mean_ms, int *frames);
 
 /* Form 2 - one process, `n_devices` GPUs, the frame wanted in host memory: what a host shaped like
  * main.rs holds (Engine{..} at main.rs:64-71, compute_lightmaps at :73, render into the locked

@@ -22,6 +22,9 @@ class Material(ctypes.Structure):
 _F3 = POINTER(c_float)
 # rm_allgather_fn: (user, d_send, d_recv, bytes_per_rank, hip_stream) -> status
 ALLGATHER_FN = CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p)
+# rm_gather_fn: (user, d_send, d_recv, bytes_per_rank, root, hip_stream) -> status
+GATHER_FN = CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p)
+RM_EXCHANGE_ALL_GATHER, RM_EXCHANGE_PRESENTER = 0, 1
 
 # name -> (restype, argtypes); mirrors include/rm.h one to one
 SIGNATURES = {
@@ -78,6 +81,7 @@ SIGNATURES = {
     "rm_engine_split_tiles": (c_int, [c_void_p, POINTER(c_uint32)]),
     "rm_engine_get_stats": (c_int, [c_void_p, POINTER(c_uint64)]),
     "rm_engine_reset_stats": (c_int, [c_void_p]),
+    "rm_engine_shader_clock": (c_int, [c_void_p, c_int, POINTER(c_double)]),
     "rm_engine_synchronize": (c_int, [c_void_p]),
     "rm_group_unique_id": (c_int, [POINTER(c_uint8)]),
     "rm_group_create": (c_void_p, [c_void_p, POINTER(c_uint8), c_int, c_int, c_int]),
@@ -89,6 +93,11 @@ SIGNATURES = {
     "rm_group_wait": (c_int, [c_void_p]),
     "rm_group_set_timing": (c_int, [c_void_p, c_int]),
     "rm_group_render_time": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int)]),
+    "rm_group_exchange_time": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int)]),
+    "rm_group_set_exchange": (c_int, [c_void_p, c_int]),
+    "rm_group_next_presenter": (c_int, [c_void_p, POINTER(c_int)]),
+    "rm_group_set_custom_gather": (c_int, [c_void_p, GATHER_FN, c_void_p]),
+    "rm_group_communicators": (c_int, [c_void_p, POINTER(c_int)]),
     "rm_multi_create": (c_void_p, [c_void_p, c_int, c_int, c_int, POINTER(c_int), c_int]),
     "rm_multi_destroy": (None, [c_void_p]),
     "rm_multi_device_count": (c_int, [c_void_p]),

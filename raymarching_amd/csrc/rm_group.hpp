@@ -46,6 +46,13 @@ struct RcclApi {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    // optional (absent from old builds): a communicator per frame in flight, and the gather to one rank
+    decltype(&ncclCommSplit) CommSplit = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
 };
 
 // The process's RCCL: the copy already loaded if there is one (a host such as PyTorch brings its
@@ -61,17 +68,25 @@ static const RcclApi *rccl_api(std::string &why) {
         return nullptr;
     }
     void *h = nullptr;
-    for (const char *name : {"librccl.so.1", "librccl.so"}) {
-        h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
-        if (h) break;
-    }
-    if (!h)
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    // RM_RCCL_LIBRARY names the one file to take instead (a build of RCCL kept elsewhere; tests point it
+    // at a file that does not exist to walk the failure path below)
+    const char *named = getenv("RM_RCCL_LIBRARY");
+    if (named && *named) {
+        h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+    } else {
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
             if (h) break;
         }
+        if (!h)
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (h) break;
+            }
+    }
     if (!h) {
-        error = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "not found");
+        const char *why_dl = dlerror();  // (one call: it hands the message out once and clears it)
+        error = std::string("librccl.so could not be loaded: ") + (why_dl ? why_dl : "not found");
         why = error;
         return nullptr;
     }
@@ -87,6 +102,12 @@ static const RcclApi *rccl_api(std::string &why) {
         why = error;
         return nullptr;
     }
+    a.CommSplit = reinterpret_cast<decltype(a.CommSplit)>(dlsym(h, "ncclCommSplit"));
+    a.Gather = reinterpret_cast<decltype(a.Gather)>(dlsym(h, "ncclGather"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(h, "ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(h, "ncclRecv"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     api = a;
     return &api;
 }
@@ -97,9 +118,12 @@ constexpr int kGroupTimedFrames = 256;  // render-kernel timings kept (a ring)
 
 struct GroupSlot {
     hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;            // the communicator this slot's frames travel through (RCCL groups)
+    bool own_comm = false;                // split from the group's for this slot: destroyed with it
     unsigned char *d_strips = nullptr;    // this rank's strips, 4 bytes per pixel, compact
     unsigned char *d_wire = nullptr;      // the same as 3 bytes per pixel (packed exchange only)
     unsigned char *d_gathered = nullptr;  // every rank's strips as the all-gather leaves them
+    unsigned char *d_gathered4 = nullptr;   // every rank's strips, 4 bytes per pixel, on the presenter of a frame (allocated on first use)
     unsigned char *d_unfiltered = nullptr;  // the gathered frame in row order ahead of FXAA (allocated on first use)
 };
 
@@ -108,8 +132,13 @@ struct rm_group {
     int rank = 0, world = 1, in_flight = 1;
     const RcclApi *api = nullptr;
     ncclComm_t comm = nullptr;
+    int n_comms = 0;                   // communicators the frames use (0: custom exchange)
     rm_allgather_fn custom = nullptr;  // the host's exchange instead of RCCL
     void *custom_user = nullptr;
+    rm_gather_fn custom_gather = nullptr;
+    void *custom_gather_user = nullptr;
+    int exchange = RM_EXCHANGE_ALL_GATHER;
+    unsigned long long frames = 0;  // frames issued in the current exchange mode: frame f's presenter is rank f mod world
     int strips_per_rank = 0;
     size_t band_pixels = 0;  // pixels of one rank's part (padded to whole strips)
     bool packed = false;     // 3 bytes per pixel on the wire
@@ -118,35 +147,84 @@ struct rm_group {
     // lightmap exchange: one rank's padded slice and the gathered whole, [per_patches * world][3] floats
     int per_patches = 0;
     float *d_slice = nullptr, *d_whole = nullptr;
-    // optional timing of the render kernel alone
+    // what the group changed on its engine, to be put back when it goes
+    bool retuned = false, saved_split_on = true;
+    unsigned saved_dense_tiles = 0;
+    // optional timing of the render kernel and of the exchange alone
     bool timing = false;
     int timed = 0;
-    hipEvent_t ev0[kGroupTimedFrames] = {}, ev1[kGroupTimedFrames] = {};
+    hipEvent_t ev0[kGroupTimedFrames] = {}, ev1[kGroupTimedFrames] = {};  // around the render launch
+    hipEvent_t ex0[kGroupTimedFrames] = {}, ex1[kGroupTimedFrames] = {};  // around the collective
 };
 
-static int group_all_gather(rm_group *g, const void *d_send, void *d_recv, size_t count, bool floats, hipStream_t stream) {
+static int group_all_gather(rm_group *g, ncclComm_t comm, const void *d_send, void *d_recv, size_t count, bool floats, hipStream_t stream) {
     if (g->custom) {
         const int rc = g->custom(g->custom_user, d_send, d_recv, count * (floats ? sizeof(float) : 1), stream);
         if (rc) return fail(RM_ERR_HIP, "the host's all-gather function failed with " + std::to_string(rc));
         return RM_OK;
     }
-    const ncclResult_t r = g->api->AllGather(d_send, d_recv, count, floats ? ncclFloat32 : ncclUint8, g->comm, stream);
+    const ncclResult_t r = g->api->AllGather(d_send, d_recv, count, floats ? ncclFloat32 : ncclUint8, comm, stream);
     if (r != ncclSuccess) return fail(RM_ERR_HIP, std::string("ncclAllGather failed: ") + g->api->GetErrorString(r));
+    return RM_OK;
+}
+
+// `count` bytes of every rank, rank 0's first, into `d_recv` on rank `root` (unused elsewhere).
+static int group_gather_bytes(rm_group *g, ncclComm_t comm, const void *d_send, void *d_recv, size_t count, int root, hipStream_t stream) {
+    if (g->custom) {
+        int rc;
+        if (g->custom_gather)
+            rc = g->custom_gather(g->custom_gather_user, d_send, g->rank == root ? d_recv : nullptr, count, root, stream);
+        else  // the host gave an all-gather only: every rank receives, the presenter alone goes on to use it
+            rc = g->custom(g->custom_user, d_send, d_recv, count, stream);
+        if (rc) return fail(RM_ERR_HIP, "the host's gather function failed with " + std::to_string(rc));
+        return RM_OK;
+    }
+    const RcclApi *api = g->api;
+    ncclResult_t r;
+    if (api->Gather) {
+        r = api->Gather(d_send, g->rank == root ? d_recv : nullptr, count, ncclUint8, root, comm, stream);
+    } else if (api->Send && api->Recv && api->GroupStart && api->GroupEnd) {
+        // the same as one group of point-to-point operations: every rank sends to the root, the root
+        // receives every rank's part where it belongs
+        r = api->GroupStart();
+        if (r == ncclSuccess) r = api->Send(d_send, count, ncclUint8, root, comm, stream);
+        if (g->rank == root)
+            for (int p = 0; p < g->world && r == ncclSuccess; p++)
+                r = api->Recv(static_cast<unsigned char *>(d_recv) + (size_t)p * count, count, ncclUint8, p, comm, stream);
+        const ncclResult_t end = api->GroupEnd();
+        if (r == ncclSuccess) r = end;
+    } else {
+        return fail(RM_ERR_UNSUPPORTED, "this librccl.so has neither ncclGather nor ncclSend/ncclRecv");
+    }
+    if (r != ncclSuccess) return fail(RM_ERR_HIP, std::string("the gather to rank ") + std::to_string(root) + " failed: " + api->GetErrorString(r));
     return RM_OK;
 }
 
 static void group_free(rm_group *g) {
     if (!g) return;
-    (void)hipSetDevice(g->e->device);
+    rm_engine *e = g->e;
+    (void)hipSetDevice(e->device);
     for (GroupSlot &s : g->slot) {
         if (s.stream) {
             (void)hipStreamSynchronize(s.stream);
-            auto &att = g->e->attached_streams;
+            auto &att = e->attached_streams;
             att.erase(std::remove(att.begin(), att.end(), s.stream), att.end());
+            // the launch plan the stream's frames had goes with it (a later stream may get the same handle)
+            for (unsigned i = 0; i < 8; i++)
+                if (e->plan_taken[i] && e->plan_stream[i] == s.stream) {
+                    e->plan_taken[i] = false;
+                    e->plan_stream[i] = nullptr;
+                    e->plan_launches[i] = 0;
+                    e->plan_key[i] = rm_engine::PlanKey();
+                    if (e->last_plan_count == e->plan_count_word[i]) e->last_plan_count = nullptr;
+                    e->plan_count_word[i] = nullptr;
+                }
         }
+        if (s.own_comm && s.comm) (void)g->api->CommDestroy(s.comm);
         (void)hipFree(s.d_strips);
         (void)hipFree(s.d_wire);
         (void)hipFree(s.d_gathered);
+        (void)hipFree(s.d_gathered4);
         (void)hipFree(s.d_unfiltered);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
@@ -155,9 +233,32 @@ static void group_free(rm_group *g) {
     for (int i = 0; i < kGroupTimedFrames; i++) {
         if (g->ev0[i]) (void)hipEventDestroy(g->ev0[i]);
         if (g->ev1[i]) (void)hipEventDestroy(g->ev1[i]);
+        if (g->ex0[i]) (void)hipEventDestroy(g->ex0[i]);
+        if (g->ex1[i]) (void)hipEventDestroy(g->ex1[i]);
     }
     if (g->comm) (void)g->api->CommDestroy(g->comm);
+    if (g->retuned) {
+        e->split_on = g->saved_split_on;
+        e->dense_tiles = g->saved_dense_tiles;
+    }
     delete g;
+}
+
+// How the engine launches frames while the group lives (put back by group_free): applied once the
+// group stands, so that a creation that fails leaves the engine as it was.
+// With several frames in flight the machine is busy while a frame's slow tiles finish, and the
+// quarter waves of rm_engine_set_tile_splitting cost throughput - unless a rank's share is so
+// small that even three of them leave the machine waiting for their slow tiles (measured on
+// shares of the 3840x2160 frame, two or three in flight: a half and a quarter - 64800 and
+// 32400 tiles - are 10 % slower with the plans, an eighth - 16200 tiles - 6-23 % faster).
+static void group_retune_engine(rm_group *g) {
+    rm_engine *e = g->e;
+    g->saved_split_on = e->split_on;
+    g->saved_dense_tiles = e->dense_tiles;
+    g->retuned = true;
+    const long share_tiles = (long)g->strips_per_rank * ((e->W + TILE - 1) / TILE);
+    if (g->in_flight > 1 && share_tiles > 20000) e->split_on = false;
+    if (g->in_flight > 1 && !getenv("RM_DENSE_TILES")) e->dense_tiles = g->in_flight >= 3 ? kOverlapDenseTiles3 : kOverlapDenseTiles2;
 }
 
 static rm_group *group_build(rm_engine *e, int rank, int world, int frames_in_flight) {
@@ -176,14 +277,6 @@ static rm_group *group_build(rm_engine *e, int rank, int world, int frames_in_fl
     g->in_flight = frames_in_flight;
     const int strips = (e->H + RM_STRIP_ROWS - 1) / RM_STRIP_ROWS;
     g->strips_per_rank = (strips + world - 1) / world;
-    // With several frames in flight the machine is busy while a frame's slow tiles finish, and the
-    // quarter waves of rm_engine_set_tile_splitting cost throughput - unless a rank's share is so
-    // small that even three of them leave the machine waiting for their slow tiles (measured on
-    // shares of the 3840x2160 frame, two or three in flight: a half and a quarter - 64800 and
-    // 32400 tiles - are 10 % slower with the plans, an eighth - 16200 tiles - 6-23 % faster).
-    const long share_tiles = (long)g->strips_per_rank * ((e->W + TILE - 1) / TILE);
-    if (frames_in_flight > 1 && share_tiles > 20000) e->split_on = false;
-    if (frames_in_flight > 1 && !getenv("RM_DENSE_TILES")) e->dense_tiles = frames_in_flight >= 3 ? kOverlapDenseTiles3 : kOverlapDenseTiles2;
     g->band_pixels = (size_t)g->strips_per_rank * RM_STRIP_ROWS * e->W;
     g->packed = e->W % 4 == 0 && e->H <= 65535;
     const size_t wire = g->packed ? 3 : 4;
@@ -225,12 +318,12 @@ static int group_gather_patches(rm_group *g, const float *d_src, float *d_dst) {
     // Equal slices that end up in another array travel as they lie: from this rank's part of the source
     // straight into the destination, no staging copies.
     if ((size_t)g->per_patches * g->world == (size_t)e->n_patches && d_src != d_dst)
-        return group_all_gather(g, d_src + (size_t)p0 * 3, d_dst, per, true, e->stream);
+        return group_all_gather(g, g->comm, d_src + (size_t)p0 * 3, d_dst, per, true, e->stream);
     // otherwise slices are equal parts on the wire; the tail of the last ranks' is padding
     HIP_TRY(hipMemsetAsync(g->d_slice, 0, per * sizeof(float), e->stream));
     if (p1 > p0)
         HIP_TRY(hipMemcpyAsync(g->d_slice, d_src + (size_t)p0 * 3, (size_t)(p1 - p0) * 3 * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
-    if (int rc = group_all_gather(g, g->d_slice, g->d_whole, per, true, e->stream)) return rc;
+    if (int rc = group_all_gather(g, g->comm, g->d_slice, g->d_whole, per, true, e->stream)) return rc;
     HIP_TRY(hipMemcpyAsync(d_dst, g->d_whole, (size_t)e->n_patches * 3 * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
     return RM_OK;
 }
@@ -273,6 +366,32 @@ rm_group *rm_group_create(rm_engine *engine, const uint8_t id[RM_GROUP_ID_BYTES]
         group_free(g);
         return nullptr;
     }
+    // A communicator per frame in flight.  RCCL orders what is launched through one communicator, on
+    // whatever stream: with one for all, frame f+1's exchange would start only after frame f's has
+    // finished, although the two are on streams of their own - and the gathers of consecutive frames
+    // to different presenters, which use different links, could never overlap.  Every rank issues its
+    // frames in the same order, so the communicators are used in the same order everywhere.
+    // (ncclCommSplit is collective over the parent, like the call above.  RM_GROUP_SHARED_COMM=1, the
+    // same on every rank, keeps the one communicator.)
+    g->n_comms = 1;
+    g->slot[0].comm = g->comm;
+    const char *shared = getenv("RM_GROUP_SHARED_COMM");
+    const bool split = api->CommSplit && !(shared && atoi(shared) != 0);
+    for (int i = 1; i < frames_in_flight; i++) {
+        g->slot[i].comm = g->comm;
+        if (!split) continue;
+        ncclComm_t c = nullptr;
+        const ncclResult_t rs = api->CommSplit(g->comm, 0, rank, &c, nullptr);
+        if (rs != ncclSuccess || !c) {
+            fail(RM_ERR_HIP, std::string("ncclCommSplit failed: ") + api->GetErrorString(rs));
+            group_free(g);
+            return nullptr;
+        }
+        g->slot[i].comm = c;
+        g->slot[i].own_comm = true;
+        g->n_comms++;
+    }
+    group_retune_engine(g);
     return g;
 }
 
@@ -285,6 +404,7 @@ rm_group *rm_group_create_custom(rm_engine *engine, int rank, int world, int fra
     if (!g) return nullptr;
     g->custom = all_gather;
     g->custom_user = user;
+    group_retune_engine(g);
     return g;
 }
 
@@ -299,15 +419,50 @@ int rm_group_info(const rm_group *g, int *rank, int *world, int *strips_per_rank
     return RM_OK;
 }
 
+int rm_group_set_exchange(rm_group *g, int mode) {
+    if (!g || (mode != RM_EXCHANGE_ALL_GATHER && mode != RM_EXCHANGE_PRESENTER)) return fail(RM_ERR_INVALID, "rm_group_set_exchange: unknown mode");
+    if (int rc = rm_group_wait(g)) return rc;
+    g->exchange = mode;
+    g->frames = 0;
+    return RM_OK;
+}
+
+int rm_group_next_presenter(const rm_group *g, int *rank) {
+    if (!g || !rank) return fail(RM_ERR_INVALID, "NULL argument");
+    *rank = g->exchange == RM_EXCHANGE_PRESENTER ? (int)(g->frames % (unsigned long long)g->world) : -1;
+    return RM_OK;
+}
+
+int rm_group_set_custom_gather(rm_group *g, rm_gather_fn gather, void *user) {
+    if (!g) return fail(RM_ERR_INVALID, "NULL group");
+    if (!g->custom) return fail(RM_ERR_INVALID, "rm_group_set_custom_gather: the group exchanges through RCCL");
+    g->custom_gather = gather;
+    g->custom_gather_user = user;
+    return RM_OK;
+}
+
+int rm_group_communicators(const rm_group *g, int *count) {
+    if (!g || !count) return fail(RM_ERR_INVALID, "NULL argument");
+    *count = g->n_comms;
+    return RM_OK;
+}
+
 int rm_group_frame(rm_group *g, void *d_bgra_frame, int fxaa, int32_t mouse_x, int32_t mouse_y, const float rel_move[3], int32_t scroll) {
-    if (!g || !d_bgra_frame) return fail(RM_ERR_INVALID, "NULL argument");
+    if (!g) return fail(RM_ERR_INVALID, "NULL argument");
+    const int presenter = g->exchange == RM_EXCHANGE_PRESENTER ? (int)(g->frames % (unsigned long long)g->world) : -1;
+    const bool lands_here = presenter < 0 || presenter == g->rank;
+    if (lands_here && !d_bgra_frame) return fail(RM_ERR_INVALID, "NULL frame on a rank the frame lands on");
     rm_engine *e = g->e;
     int rc = rm_engine_input(e, mouse_x, mouse_y, rel_move, scroll);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
     GroupSlot &s = g->slot[g->next_slot];
+    if (fxaa && lands_here && !s.d_unfiltered) HIP_TRY(dev_alloc(&s.d_unfiltered, (size_t)e->W * e->H * 4));
+    // (a host that supplied an all-gather only makes every rank receive)
+    const bool receives = presenter == g->rank || (presenter >= 0 && g->custom && !g->custom_gather);
+    if (receives && !s.d_gathered4) HIP_TRY(dev_alloc(&s.d_gathered4, g->band_pixels * 4 * g->world));
     g->next_slot = (g->next_slot + 1) % g->in_flight;
-    if (fxaa && !s.d_unfiltered) HIP_TRY(dev_alloc(&s.d_unfiltered, (size_t)e->W * e->H * 4));
+    g->frames++;
     // Everything of this frame goes to the slot's stream, in order; the frame that used the slot's
     // buffers before it is ahead of it on the same stream.
     hipStream_t own = e->stream;
@@ -318,30 +473,47 @@ int rm_group_frame(rm_group *g, void *d_bgra_frame, int fxaa, int32_t mouse_x, i
             if (!g->ev0[t]) {
                 HIP_TRY(hipEventCreate(&g->ev0[t]));
                 HIP_TRY(hipEventCreate(&g->ev1[t]));
+                HIP_TRY(hipEventCreate(&g->ex0[t]));
+                HIP_TRY(hipEventCreate(&g->ex1[t]));
             }
             HIP_TRY(hipEventRecord(g->ev0[t], s.stream));
         }
         if (int r = rm_engine_render_strips_device(e, s.d_strips, (size_t)e->W * 4, g->rank, g->world, g->strips_per_rank)) return r;
-        if (g->timing) {
-            HIP_TRY(hipEventRecord(g->ev1[t], s.stream));
-            g->timed++;
-        }
+        if (g->timing) HIP_TRY(hipEventRecord(g->ev1[t], s.stream));
         void *frame = fxaa ? s.d_unfiltered : static_cast<unsigned char *>(d_bgra_frame);
-        if (g->packed) {
+        const auto reorder = [&](const unsigned char *gathered) {
+            hipLaunchKernelGGL(reorder_strips_kernel, dim3((e->W + 255) / 256, e->H), dim3(256), 0, s.stream,
+                               reinterpret_cast<const unsigned *>(gathered), static_cast<unsigned *>(frame), e->W, e->H, g->world,
+                               g->strips_per_rank);
+        };
+        if (presenter >= 0) {
+            // the strips travel as rendered, 4 bytes per pixel: a link carries one frame in `world`, so the
+            // packing pass would cost every rank more time than the fourth byte costs the links
+            if (g->timing) HIP_TRY(hipEventRecord(g->ex0[t], s.stream));
+            if (int r = group_gather_bytes(g, s.comm, s.d_strips, s.d_gathered4, g->band_pixels * 4, presenter, s.stream)) return r;
+            if (g->timing) HIP_TRY(hipEventRecord(g->ex1[t], s.stream));
+            if (lands_here) {
+                reorder(s.d_gathered4);
+                HIP_TRY(hipGetLastError());
+            }
+        } else if (g->packed) {
             // byte 3 of every rendered pixel is 0 (engine.rs:116-126): strips cross the links as B,G,R triples
             if (int r = rm_engine_pack_bgr_device(e, s.d_strips, s.d_wire, g->band_pixels)) return r;
-            if (int r = group_all_gather(g, s.d_wire, s.d_gathered, g->band_pixels * 3, false, s.stream)) return r;
+            if (g->timing) HIP_TRY(hipEventRecord(g->ex0[t], s.stream));
+            if (int r = group_all_gather(g, s.comm, s.d_wire, s.d_gathered, g->band_pixels * 3, false, s.stream)) return r;
+            if (g->timing) HIP_TRY(hipEventRecord(g->ex1[t], s.stream));
             if (int r = rm_engine_unpack_bgr_strips_device(e, s.d_gathered, frame, g->world, g->strips_per_rank)) return r;
         } else {
-            if (int r = group_all_gather(g, s.d_strips, s.d_gathered, g->band_pixels * 4, false, s.stream)) return r;
-            hipLaunchKernelGGL(reorder_strips_kernel, dim3((e->W + 255) / 256, e->H), dim3(256), 0, s.stream,
-                               reinterpret_cast<const unsigned *>(s.d_gathered), static_cast<unsigned *>(frame), e->W, e->H, g->world,
-                               g->strips_per_rank);
+            if (g->timing) HIP_TRY(hipEventRecord(g->ex0[t], s.stream));
+            if (int r = group_all_gather(g, s.comm, s.d_strips, s.d_gathered, g->band_pixels * 4, false, s.stream)) return r;
+            if (g->timing) HIP_TRY(hipEventRecord(g->ex1[t], s.stream));
+            reorder(s.d_gathered);
             HIP_TRY(hipGetLastError());
         }
+        if (g->timing) g->timed++;
         // FXAA reads up to four rows below and one above a pixel (fxaa.txt:7-8,80-97): it runs on the
         // gathered frame, so the strips need no halo and stay interleaved (even load)
-        if (fxaa)
+        if (fxaa && lands_here)
             if (int r = rm_engine_fxaa_device(e, s.d_unfiltered, d_bgra_frame, 0, e->H)) return r;
         return RM_OK;
     };
@@ -364,20 +536,22 @@ int rm_group_set_timing(rm_group *g, int on) {
     return RM_OK;
 }
 
-int rm_group_render_time(rm_group *g, double *mean_ms, int *frames) {
+static int group_mean_ms(rm_group *g, hipEvent_t *from, hipEvent_t *to, double *mean_ms, int *frames) {
     if (!g || !mean_ms) return fail(RM_ERR_INVALID, "NULL argument");
     if (int rc = rm_group_wait(g)) return rc;
     const int n = std::min(g->timed, kGroupTimedFrames);
     double sum = 0.0;
     for (int i = 0; i < n; i++) {
         float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, g->ev0[i], g->ev1[i]));
+        HIP_TRY(hipEventElapsedTime(&ms, from[i], to[i]));
         sum += ms;
     }
     *mean_ms = n ? sum / n : 0.0;
     if (frames) *frames = n;
     return RM_OK;
 }
+int rm_group_render_time(rm_group *g, double *mean_ms, int *frames) { return group_mean_ms(g, g ? g->ev0 : nullptr, g ? g->ev1 : nullptr, mean_ms, frames); }
+int rm_group_exchange_time(rm_group *g, double *mean_ms, int *frames) { return group_mean_ms(g, g ? g->ex0 : nullptr, g ? g->ex1 : nullptr, mean_ms, frames); }
 
 // Engine::compute_lightmaps (engine.rs:246-326) over the group: every rank builds the clouds and the
 // direct lighting (cheap), computes the form factors of its own receiver patches once, and per bounce

@@ -965,13 +965,33 @@ __global__ __launch_bounds__(256) void unpack_bgr_strips_kernel(const unsigned *
     dst[(size_t)y * W4 + g] = p;
 }
 
+// ---- the shader clock, measured ------------------------------------------------
+
+// One wave reads the shader-clock cycle counter and the constant-rate counter (100 MHz), spins until
+// `ticks` of the latter have passed and reads both again: cycles per tick is the clock the vector
+// units ran at meanwhile.  The loop ends by itself: the constant-rate counter never stops.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *out, unsigned ticks) {
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    unsigned long long t1;
+    do {
+        __builtin_amdgcn_s_sleep(8);
+        t1 = wall_clock64();
+    } while (t1 - t0 < (unsigned long long)ticks);
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = t1 - t0;
+    }
+}
+
 // ===========================================================================
 // Host runtime
 // ===========================================================================
 
 // Static scratch for rm_engine_compute_lightmaps_static: four [NP][3] float arrays (each rounded up
 // to 64 floats) and the form-factor matrix (rad_ft_floats(NP) floats) for NP <= RM_STATIC_MAX_PATCHES.  Every GPU the
-// library runs on holds its own copy (4.05 MiB) at its own address until the process ends.  In host
+// library runs on holds its own copy (4.10 MiB) at its own address until the process ends.  In host
 // code the name below is only a handle for hipGetSymbolAddress: the address kernels and memsets are
 // given is the one static_scratch_of() returns for the current device.
 constexpr size_t kStaticCloudFloats = ((size_t)RM_STATIC_MAX_PATCHES * 3 + 63) & ~(size_t)63;
@@ -981,6 +1001,9 @@ static __device__ __align__(256) float scratch[kStaticScratchFloats];
 constexpr int kMaxDevices = 64;
 static std::mutex g_scratch_mutex;
 static float *g_scratch_ptr[kMaxDevices];  // per device, looked up once
+// One precompute at a time works in a device's copy of the array: calls from several engines (or
+// threads) on one GPU take turns instead of overwriting each other's clouds and form factors.
+static std::mutex g_scratch_in_use[kMaxDevices];
 
 // The address of `scratch` on `device`, which must be the current device.
 static hipError_t static_scratch_of(int device, float **out) {
@@ -1127,6 +1150,8 @@ struct rm_engine {
     bool rad_begun = false;
     float *d_sample_pos = nullptr;  // [n_patches][3]: the point cloud of engine.rs:269-273, uploaded at creation
     bool sample_pos_ok = false;     // false: some lightmapped type has no sample positions
+    hipStream_t clock_stream = nullptr;     // rm_engine_shader_clock: beside whatever the engine's streams run
+    unsigned long long *d_clock = nullptr;  // its two counter differences
     float *scratch = nullptr;  // this device's copy of the library's static scratch array
     std::vector<hipStream_t> attached_streams;  // streams of rm_group frames in flight on this engine
     // the two-pass frame (an experiment, RM_TWO_PASS=1 when the engine is created)
@@ -1662,6 +1687,8 @@ static void engine_free(rm_engine *e) {
         if (e->ev_band_copied[b]) (void)hipEventDestroy(e->ev_band_copied[b]);
     }
     if (e->xfer_stream) (void)hipStreamDestroy(e->xfer_stream);
+    if (e->clock_stream) (void)hipStreamDestroy(e->clock_stream);
+    (void)hipFree(e->d_clock);
     (void)hipFree(e->d_patch_obj);
     (void)hipFree(e->d_queue);
     (void)hipFree(e->d_queue_count);
@@ -2050,11 +2077,15 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
     // plan's flags are one per frame tile.)
     if (e->split_on && e->split_threshold > 0 && grid.x <= frame_tiles) {
         if (!e->d_tile_cost) {
+            // (cleared before this call returns: the other streams that launch frames of this engine keep
+            // their plans in other parts of the same buffers, and nothing else would order their first plan
+            // after a clearing enqueued on this launch's stream)
             HIP_TRY(dev_alloc(&e->d_tile_cost, frame_tiles * 4));
-            HIP_TRY(hipMemsetAsync(e->d_tile_cost, 0, frame_tiles * 4 * sizeof(unsigned), e->stream));
+            HIP_TRY(hipMemset(e->d_tile_cost, 0, frame_tiles * 4 * sizeof(unsigned)));
             HIP_TRY(dev_alloc(&e->d_plan_words, (size_t)kPlanRing * kPlanStride));
-            HIP_TRY(hipMemsetAsync(e->d_plan_words, 0, (size_t)kPlanRing * kPlanStride * sizeof(unsigned), e->stream));
+            HIP_TRY(hipMemset(e->d_plan_words, 0, (size_t)kPlanRing * kPlanStride * sizeof(unsigned)));
             HIP_TRY(dev_alloc(&e->d_plan_flags, (size_t)kPlanRing * frame_tiles));
+            HIP_TRY(hipDeviceSynchronize());
         }
         // A plan is written and read in the order of one stream, so each stream that launches frames has a
         // plan of its own (launches on one stream cannot overlap); a ninth stream's launches go unplanned.
@@ -2634,6 +2665,8 @@ int rm_engine_compute_lightmaps_static(rm_engine *e, int bounces) {
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_ = sync_view(e)) return rc_;
     if (int rc_ = quiesce_frames_in_flight(e)) return rc_;
+    // (held until the stream has drained below: the call is synchronous anyway)
+    std::lock_guard<std::mutex> in_use(g_scratch_in_use[e->device]);
     // the scratch array, cut up for NP patches: four [NP][3] arrays, then FT (rad_ft_floats(NP) floats) on a 256-byte boundary
     const size_t cloud = ((size_t)NP * 3 + 63) & ~(size_t)63;
     RadBuffers b;
@@ -2791,6 +2824,22 @@ int rm_engine_reset_stats(rm_engine *e) {
     HIP_TRY(hipSetDevice(e->device));
     if (int rc_ = sync_view(e)) return rc_;
     HIP_TRY(hipMemsetAsync(e->d_stats, 0, sizeof(uint64_t) * kStatSlots, e->stream));
+    return RM_OK;
+}
+
+int rm_engine_shader_clock(rm_engine *e, int microseconds, double *mhz) {
+    if (!e || !mhz || microseconds < 1 || microseconds > 100000) return fail(RM_ERR_INVALID, "rm_engine_shader_clock: 1 to 100000 microseconds");
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->clock_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->clock_stream, hipStreamNonBlocking));
+        HIP_TRY(dev_alloc(&e->d_clock, 2));
+    }
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, e->clock_stream, e->d_clock, (unsigned)microseconds * 100u);
+    HIP_TRY(hipGetLastError());
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(v, e->d_clock, sizeof(v), hipMemcpyDeviceToHost, e->clock_stream));
+    HIP_TRY(hipStreamSynchronize(e->clock_stream));
+    *mhz = v[1] ? (double)v[0] / (double)v[1] * 100.0 : 0.0;  // cycles per 10 ns tick
     return RM_OK;
 }
 

@@ -2,6 +2,7 @@
 (engine.rs:37-41, 246, 329-333) with the pixel work done by the HIP kernels.
 """
 import ctypes
+import weakref
 from ctypes import POINTER, c_float, c_int, c_int32, c_uint8, c_uint64, c_void_p
 
 import numpy as np
@@ -86,9 +87,12 @@ class Engine:
             msg = self.lib.rm_last_error()
             raise _lib.RMError(f"rm_engine_create failed: {msg.decode() if msg else ''}")
         self.handle = c_void_p(handle)
+        self._dependents = weakref.WeakSet()  # groups over this engine: they hold its streams and must go first
 
     def close(self):
         if getattr(self, "handle", None):
+            for dep in list(getattr(self, "_dependents", ())):
+                dep.close()
             self.lib.rm_engine_destroy(self.handle)
             self.handle = None
 
@@ -275,6 +279,12 @@ class Engine:
         n = ctypes.c_uint32(0)
         _lib.check(self.lib.rm_engine_split_tiles(self.handle, ctypes.byref(n)), "rm_engine_split_tiles")
         return int(n.value)
+
+    def shader_clock_mhz(self, microseconds=200):
+        """The shader clock right now (under whatever load the engine's streams carry), in MHz."""
+        mhz = ctypes.c_double()
+        _lib.check(self.lib.rm_engine_shader_clock(self.handle, int(microseconds), ctypes.byref(mhz)), "rm_engine_shader_clock")
+        return float(mhz.value)
 
     def stats(self):
         out = (c_uint64 * _lib.RM_STAT_COUNT)()

@@ -4,6 +4,7 @@ into host memory).  The reference has one process and a thread pool (rayon rows,
 these stand where its one `Engine::render` call per frame stands (main.rs:141-145).
 """
 import ctypes
+import weakref
 from ctypes import POINTER, c_double, c_int, c_uint8, c_void_p
 
 import numpy as np
@@ -23,12 +24,17 @@ def unique_id() -> bytes:
 
 class Group:
     """Rank `rank` of `world` engines, one per GPU.  `all_gather(d_send, d_recv, bytes_per_rank, hip_stream)`
-    replaces RCCL where given (rehearsals on one GPU, other transports); it returns 0 on success."""
+    replaces RCCL where given (rehearsals on one GPU, other transports); it returns 0 on success.
+    `gather(d_send, d_recv, bytes_per_rank, root, hip_stream)` is its gather-to-one-rank counterpart for
+    the "presenter" exchange (d_recv is None on ranks other than root)."""
 
-    def __init__(self, engine: Engine, rank: int, world: int, group_id: bytes = None, frames_in_flight: int = 3, all_gather=None):
+    def __init__(self, engine: Engine, rank: int, world: int, group_id: bytes = None, frames_in_flight: int = 3, all_gather=None,
+                 gather=None):
         self.lib = _lib.load()
         self.engine = engine
         self.rank, self.world = rank, world
+        self._callback_error = None
+        self.handle = None
         if all_gather is not None:
             def _cb(user, d_send, d_recv, nbytes, stream):
                 try:
@@ -37,7 +43,6 @@ class Group:
                     self._callback_error = exc
                     return 1
 
-            self._callback_error = None
             self._cb = _lib.ALLGATHER_FN(_cb)  # kept alive as long as the group
             handle = self.lib.rm_group_create_custom(engine.handle, rank, world, frames_in_flight, self._cb, None)
         else:
@@ -49,11 +54,36 @@ class Group:
             msg = self.lib.rm_last_error()
             raise _lib.RMError(f"rm_group_create failed: {msg.decode() if msg else ''}")
         self.handle = c_void_p(handle)
+        engine._dependents.add(self)  # the engine closes its groups before itself
+        if gather is not None:
+            def _gcb(user, d_send, d_recv, nbytes, root, stream):
+                try:
+                    return int(gather(d_send, d_recv, nbytes, root, stream) or 0)
+                except Exception as exc:
+                    self._callback_error = exc
+                    return 1
+
+            self._gcb = _lib.GATHER_FN(_gcb)
+            self._check(self.lib.rm_group_set_custom_gather(self.handle, self._gcb, None), "rm_group_set_custom_gather")
+
+    def _check(self, rc, what):
+        """_lib.check, with an exception raised inside the host's exchange function brought back out."""
+        if rc != 0 and self._callback_error is not None:
+            exc, self._callback_error = self._callback_error, None
+            msg = self.lib.rm_last_error()
+            raise _lib.RMError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}") from exc
+        _lib.check(rc, what)
 
     def close(self):
         if getattr(self, "handle", None):
-            self.lib.rm_group_destroy(self.handle)
+            if getattr(self.engine, "handle", None):
+                self.lib.rm_group_destroy(self.handle)
+            # (an engine that is already gone took its device memory along; there is nothing left to release safely)
             self.handle = None
+            try:
+                self.engine._dependents.discard(self)
+            except Exception:
+                pass
 
     def __del__(self):
         try:
@@ -66,16 +96,34 @@ class Group:
         _lib.check(self.lib.rm_group_info(self.handle, ctypes.byref(r), ctypes.byref(w), ctypes.byref(s), ctypes.byref(b)), "rm_group_info")
         return {"rank": r.value, "world": w.value, "strips_per_rank": s.value, "bytes_per_pixel_exchanged": b.value}
 
+    def communicators(self):
+        """RCCL communicators the frames travel through (one per frame in flight; 0 for a custom exchange)."""
+        n = c_int()
+        _lib.check(self.lib.rm_group_communicators(self.handle, ctypes.byref(n)), "rm_group_communicators")
+        return n.value
+
+    def set_exchange(self, mode):
+        """'all_gather' (every rank receives every frame) or 'presenter' (frame f lands on rank f mod world)."""
+        code = {"all_gather": _lib.RM_EXCHANGE_ALL_GATHER, "presenter": _lib.RM_EXCHANGE_PRESENTER}[mode]
+        self._check(self.lib.rm_group_set_exchange(self.handle, code), "rm_group_set_exchange")
+
+    def next_presenter(self):
+        """The rank the next frame lands on, or -1 for every rank."""
+        r = c_int()
+        _lib.check(self.lib.rm_group_next_presenter(self.handle, ctypes.byref(r)), "rm_group_next_presenter")
+        return r.value
+
     def compute_lightmaps(self, bounces=4):
-        _lib.check(self.lib.rm_group_compute_lightmaps(self.handle, bounces), "rm_group_compute_lightmaps")
+        self._check(self.lib.rm_group_compute_lightmaps(self.handle, bounces), "rm_group_compute_lightmaps")
 
     def frame(self, d_frame: int, fxaa=False, mouse_x=0, mouse_y=0, rel_move=(0.0, 0.0, 0.0), scroll=0):
-        """Enqueue one frame of the group; the whole frame lands at device pointer `d_frame` on this rank."""
-        _lib.check(self.lib.rm_group_frame(self.handle, c_void_p(d_frame), 1 if fxaa else 0, mouse_x, mouse_y, _lib.f3(rel_move), scroll),
-                   "rm_group_frame")
+        """Enqueue one frame of the group; the whole frame lands at device pointer `d_frame` on this rank
+        (on the frame's presenter alone with the 'presenter' exchange; d_frame may be 0 elsewhere)."""
+        self._check(self.lib.rm_group_frame(self.handle, c_void_p(d_frame or None), 1 if fxaa else 0, mouse_x, mouse_y, _lib.f3(rel_move), scroll),
+                    "rm_group_frame")
 
     def wait(self):
-        _lib.check(self.lib.rm_group_wait(self.handle), "rm_group_wait")
+        self._check(self.lib.rm_group_wait(self.handle), "rm_group_wait")
 
     def set_timing(self, on=True):
         _lib.check(self.lib.rm_group_set_timing(self.handle, 1 if on else 0), "rm_group_set_timing")
@@ -86,6 +134,12 @@ class Group:
         _lib.check(self.lib.rm_group_render_time(self.handle, ctypes.byref(ms), ctypes.byref(n)), "rm_group_render_time")
         return ms.value, n.value
 
+    def exchange_time(self):
+        """(mean ms of the collective alone over the timed frames, number of frames)."""
+        ms, n = c_double(), c_int()
+        _lib.check(self.lib.rm_group_exchange_time(self.handle, ctypes.byref(ms), ctypes.byref(n)), "rm_group_exchange_time")
+        return ms.value, n.value
+
 
 class _BorrowedEngine(Engine):
     """An engine owned by a MultiEngine: the Engine interface without ownership of the handle."""
@@ -94,6 +148,7 @@ class _BorrowedEngine(Engine):
         self.lib = lib
         self.handle = c_void_p(handle)
         self.width, self.height, self.map_size, self.device, self.n_objects = width, height, map_size, device, n_objects
+        self._dependents = weakref.WeakSet()
 
     def close(self):
         self.handle = None

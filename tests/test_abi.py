@@ -80,3 +80,31 @@ def test_rust_binding_matches_the_header():
     from raymarching_amd import _lib
 
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+
+
+def test_a_missing_rccl_is_reported_not_crashed_on():
+    """rm_group_unique_id and rm_group_create look RCCL up at run time; where it cannot be loaded they
+    must come back with RM_ERR_UNSUPPORTED and a message (a fresh process: the lookup is cached)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from raymarching_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "buf = (ctypes.c_uint8 * _lib.RM_GROUP_ID_BYTES)()\n"
+        "rc1 = lib.rm_group_unique_id(buf)\n"
+        "msg1 = lib.rm_last_error().decode()\n"
+        "rc2 = lib.rm_group_unique_id(buf)  # the cached failure\n"
+        "msg2 = lib.rm_last_error().decode()\n"
+        "g = lib.rm_group_create(None, buf, 0, 1, 1)\n"
+        "print(rc1, rc2, bool(g)); print(msg1); print(msg2)\n"
+    )
+    env = dict(os.environ, RM_RCCL_LIBRARY="/nonexistent/librccl-not-there.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "3 3 False", lines  # RM_ERR_UNSUPPORTED twice, no group
+    assert "could not be loaded" in lines[1] and "librccl-not-there" in lines[1]
+    assert lines[2] == lines[1]
