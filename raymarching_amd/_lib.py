@@ -77,6 +77,7 @@ SIGNATURES = {
     "rm_engine_set_tetrahedral_normals": (c_int, [c_void_p, c_int]),
     "rm_engine_set_refraction": (c_int, [c_void_p, c_int]),
     "rm_engine_set_march_cap": (c_int, [c_void_p, c_int]),
+    "rm_engine_set_exact_occlusion": (c_int, [c_void_p, c_int]),
     "rm_engine_set_tile_splitting": (c_int, [c_void_p, c_int]),
     "rm_engine_split_tiles": (c_int, [c_void_p, POINTER(c_uint32)]),
     "rm_engine_get_stats": (c_int, [c_void_p, POINTER(c_uint64)]),

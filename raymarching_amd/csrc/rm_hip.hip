@@ -636,7 +636,9 @@ __device__ __forceinline__ float rad_form_pair(const RadArgs &a, const G &grp, i
     // +0 or -0 added to a sum that started at +0 leaves it as it is either way (emission values are
     // finite), so the occlusion march is run only where its outcome can show.  A wave whose 64
     // receivers all face away from the source skips it altogether.
-    const bool matters = !(open == 0.0f);
+    // (With emission values that are not finite the two cases differ - infinity * 0 is NaN where the
+    // reference's blocked pair adds nothing - and rm_engine_set_exact_occlusion makes every pair march.)
+    const bool matters = !(open == 0.0f) || scene_ref(a.sv).exact_occlusion != 0;
     float f = open;
     if (wave_any(matters)) {
         if (matters) {
@@ -702,7 +704,10 @@ __global__ void rad_form_multi_kernel(const RadArgs a, int p0, int p1, int j0, i
 // are 16 KiB, enough once eight workgroups share a compute unit; with fewer workgroups (smaller
 // lightmaps) deeper slabs keep the memory system as busy.  The order of the additions does not depend
 // on it.
-template <int CHUNK>
+// EXACT (rm_engine_set_exact_occlusion): a pair that contributes nothing keeps its marker in the slab and
+// its term is left out of the sum, as the reference's `continue` leaves it out (radiosity.rs:112,137):
+// with an emission value that is not finite, emission * 0 would be NaN instead of nothing.
+template <int CHUNK, bool EXACT = false>
 __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0, int p1) {
     // The slab lies receiver-major in LDS, a receiver's CHUNK sources side by side (rows of CHUNK + 4
     // words: 16-byte aligned, and sixteen lanes' 16-byte accesses fall on all 64 banks once), and the
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0
             for (int q = 0; q < 4; q++) {
                 // a pair that contributes nothing (-1), a row beyond the last source, a receiver beyond p1: emission * 0 = +0
                 const bool counts = valid && row + q < rows && !(pre[4 * k + q] == -1.0f);
-                v[q] = counts ? pre[4 * k + q] : 0.0f;
+                v[q] = counts ? pre[4 * k + q] : (EXACT ? -1.0f : 0.0f);
             }
             *reinterpret_cast<float4 *>(&slab[lane][row]) = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -775,6 +780,12 @@ __global__ __launch_bounds__(256) void rad_bounce_kernel(const RadArgs a, int p0
             // Sixteen steps at a time: their operands are fetched and multiplied first, then added in
             // source order, so that a step costs one addition's latency and not a round trip to LDS.
             int jj = 0;
+            if constexpr (EXACT) {
+                for (; jj < rows; jj++) {
+                    const float f = slab[lane][jj];
+                    if (!(f == -1.0f)) acc = acc + em_s[part][jj] * f;
+                }
+            }
             for (; jj + 16 <= rows; jj += 16) {
                 float term[16];
 #pragma unroll
@@ -1078,6 +1089,7 @@ struct rm_engine {
     bool ssaa = false;  // four rays per pixel (engine.rs:95-108)
     bool tetra_normals = false;  // objects.rs:142-149
     bool refraction = false;     // engine.rs:196-228
+    bool exact_occlusion = false;  // rm_engine_set_exact_occlusion
     size_t grid_entries = 0;  // list entries of the spatial index (0 = none)
 
     // device-resident scene
@@ -1177,6 +1189,7 @@ struct rm_engine {
         sv.march_cap = march_cap;
         sv.tetra_normals = tetra_normals ? 1 : 0;
         sv.refraction = refraction ? 1 : 0;
+        sv.exact_occlusion = exact_occlusion ? 1 : 0;
         sv.stats = d_stats;
         return sv;
     }
@@ -2536,7 +2549,9 @@ static int rad_bounce_on(rm_engine *e, const RadBuffers &b, int p0, int p1) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
     int chunk = ((int)grid.x >= cus && (int)grid.x <= 3 * cus) ? 192 : 128;
     if (const char *c = getenv("RM_BOUNCE_CHUNK")) chunk = atoi(c);  // tuning aid
-    if (chunk == 64)
+    if (e->exact_occlusion)
+        hipLaunchKernelGGL((rad_bounce_kernel<128, true>), grid, dim3(256), 0, e->stream, a, p0, p1);
+    else if (chunk == 64)
         hipLaunchKernelGGL(rad_bounce_kernel<64>, grid, dim3(256), 0, e->stream, a, p0, p1);
     else if (chunk == 192)
         hipLaunchKernelGGL(rad_bounce_kernel<192>, grid, dim3(256), 0, e->stream, a, p0, p1);
@@ -2774,6 +2789,13 @@ int rm_engine_set_tetrahedral_normals(rm_engine *e, int on) {
 int rm_engine_set_refraction(rm_engine *e, int on) {
     if (!e) return fail(RM_ERR_INVALID, "NULL engine");
     e->refraction = on != 0;
+    e->view_dirty = true;
+    return RM_OK;
+}
+
+int rm_engine_set_exact_occlusion(rm_engine *e, int on) {
+    if (!e) return fail(RM_ERR_INVALID, "NULL engine");
+    e->exact_occlusion = on != 0;
     e->view_dirty = true;
     return RM_OK;
 }

@@ -142,6 +142,7 @@ struct SceneView {
     int march_cap;  // 0 = none
     int tetra_normals;  // 1 = the four-point normal of objects.rs:142-149 (commented out there)
     int refraction;     // 1 = the refraction block of engine.rs:196-228 (commented out there)
+    int exact_occlusion;  // 1 = the lightmap precompute marches every patch pair, as radiosity.rs:130-141 does (see rm_engine_set_exact_occlusion)
     unsigned long long *stats;
 };
 

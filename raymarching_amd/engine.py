@@ -267,6 +267,11 @@ class Engine:
         """engine.rs:196-228: reflective objects also pass a refracted ray (index ratio 2.5)."""
         _lib.check(self.lib.rm_engine_set_refraction(self.handle, 1 if on else 0), "rm_engine_set_refraction")
 
+    def set_exact_occlusion(self, on):
+        """radiosity.rs:130-141: march every patch pair and leave blocked pairs out of the sum (matters
+        only for emission values that are not finite; see rm.h)."""
+        _lib.check(self.lib.rm_engine_set_exact_occlusion(self.handle, 1 if on else 0), "rm_engine_set_exact_occlusion")
+
     def set_march_cap(self, max_steps):
         _lib.check(self.lib.rm_engine_set_march_cap(self.handle, max_steps), "rm_engine_set_march_cap")
 

@@ -222,3 +222,54 @@ def test_lightmaps_saved_and_loaded(tmp_path, scene):
     got = np.stack([other.get_lightmap(i) for i in range(other.n_objects)])
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     other.close()
+
+
+def _scene_with_emission(scene, obj, emissive):
+    import dataclasses
+
+    objects = list(scene.objects)
+    objects[obj] = dataclasses.replace(objects[obj], material=dataclasses.replace(objects[obj].material, emissive=emissive))
+    return dataclasses.replace(scene, objects=objects)
+
+
+@pytest.mark.parametrize("emissive", [float("inf"), float("nan")])
+def test_emission_that_is_not_finite(scene, emissive):
+    """radiosity.rs:130-152 with emission values that overflow: the reference leaves a blocked patch
+    pair out of the sum and adds emission * 0 = NaN for an open pair that faces away.  With
+    rm_engine_set_exact_occlusion the precompute does exactly that (every pair marched, blocked pairs
+    skipped): same values, same NaNs.  The default takes two shortcuts that are invisible for finite
+    emission (facing-away pairs are not marched, blocked pairs add emission * 0) - this test is the
+    definition of what they do otherwise: a value may differ from the reference's only by being NaN."""
+    from raymarching_amd import Engine
+    from conftest import make_oracle
+
+    glowing = _scene_with_emission(scene, 5, emissive)  # the green wall (main.rs:185)
+    ora = make_oracle(glowing)
+    stages, _ = ora.compute_lightmaps(4, stages=True)
+    ora.close()
+    for bounces in (1, 4):
+        ref = stages[bounces]
+        assert np.isnan(ref).any() and np.isfinite(ref).any()  # the case is not trivial: NaN has spread, not everywhere
+        e = Engine(glowing, 64, 64)
+        e.set_exact_occlusion(True)
+        e.compute_lightmaps(bounces)
+        exact = np.stack([e.get_lightmap(i) for i in range(e.n_objects)])
+        e.set_exact_occlusion(False)
+        e.compute_lightmaps(bounces)
+        default = np.stack([e.get_lightmap(i) for i in range(e.n_objects)])
+        e.close()
+        assert np.array_equal(exact, ref, equal_nan=True), f"{bounces} bounces, exact occlusion"
+        same = (default == ref) | (np.isnan(default) & np.isnan(ref))
+        assert np.isnan(default[~same]).all(), f"{bounces} bounces: the shortcuts may only add NaNs"
+    # finite emission: the switch changes nothing
+    warm = _scene_with_emission(scene, 5, 0.75)
+    ora = make_oracle(warm)
+    ref = ora.compute_lightmaps(4, stages=True)[0][4]
+    ora.close()
+    e = Engine(warm, 64, 64)
+    for on in (False, True):
+        e.set_exact_occlusion(on)
+        e.compute_lightmaps(4)
+        got = np.stack([e.get_lightmap(i) for i in range(e.n_objects)])
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"finite emission, exact occlusion {on}"
+    e.close()
