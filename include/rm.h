@@ -278,6 +278,22 @@ int rm_engine_set_tetrahedral_normals(rm_engine *engine, int on);
  * rm_engine_probe_shade. */
 int rm_engine_set_refraction(rm_engine *engine, int on);
 
+/* The arithmetic of the frame kernel (rm_engine_render*, rm_group_frame, rm_multi_render without
+ * supersampling and refraction; everything else - lightmaps, FXAA, the probes - has one arithmetic).
+ *   RM_PRECISION_STRICT (default)  every operation is the reference's IEEE binary32 operation in the
+ *       reference's order, no fused multiply-adds (vector.rs:22-32, ray.rs:28-39): frames equal a strict
+ *       CPU evaluation bit for bit except where powf/atan2f enter;
+ *   RM_PRECISION_FAST  a pixel's chain of sight rays (direction, march, hit, surface normal, mirror
+ *       direction) stays strict; what a hit's colour is made of - texture and lightmap coordinates, light
+ *       terms, Phong, the soft shadow's own steps, the sums, the tone map - uses fused multiply-adds and
+ *       the hardware's one-ulp root, reciprocal, exp2 and log2.  Frames stay within the tolerance this
+ *       renderer states against the reference - at most 2/255 per channel, at least 99.9 % of the pixels
+ *       identical - and are the same bytes from run to run; they are not bit-identical to the strict tier.
+ * No counterpart in the reference, which has one arithmetic. */
+#define RM_PRECISION_STRICT 0
+#define RM_PRECISION_FAST 1
+int rm_engine_set_precision(rm_engine *engine, int precision);
+
 /* Occlusion of patch pairs in the lightmap precompute, radiosity.rs:126-152.  The reference marches an
  * occlusion ray for every pair and leaves a blocked pair out of the sum (`continue`, :137); an open
  * pair adds emission * min(max(attenuation, 0) / d^2, 2).  on = 0 (default): a pair whose attenuation

@@ -25,6 +25,7 @@ ALLGATHER_FN = CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p
 # rm_gather_fn: (user, d_send, d_recv, bytes_per_rank, root, hip_stream) -> status
 GATHER_FN = CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p)
 RM_EXCHANGE_ALL_GATHER, RM_EXCHANGE_PRESENTER = 0, 1
+RM_PRECISION_STRICT, RM_PRECISION_FAST = 0, 1
 
 # name -> (restype, argtypes); mirrors include/rm.h one to one
 SIGNATURES = {
@@ -77,6 +78,7 @@ SIGNATURES = {
     "rm_engine_set_tetrahedral_normals": (c_int, [c_void_p, c_int]),
     "rm_engine_set_refraction": (c_int, [c_void_p, c_int]),
     "rm_engine_set_march_cap": (c_int, [c_void_p, c_int]),
+    "rm_engine_set_precision": (c_int, [c_void_p, c_int]),
     "rm_engine_set_exact_occlusion": (c_int, [c_void_p, c_int]),
     "rm_engine_set_tile_splitting": (c_int, [c_void_p, c_int]),
     "rm_engine_split_tiles": (c_int, [c_void_p, POINTER(c_uint32)]),

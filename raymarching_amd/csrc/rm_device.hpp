@@ -22,6 +22,33 @@ namespace rm {
 #define RM_ABL 0
 #endif
 
+// RM_FAST = 1 builds the "fast" tier of this arithmetic (rm_fast.hip, compiled with
+// -ffp-contract=fast-honor-pragmas).  A pixel's chain of sight rays stays strict in that tier too:
+// pixel direction, march, hit object, surface normal, mirror direction.  The normal is a difference
+// of distances 0.0002 apart, which turns a last-bit change of a hit position on a sphere into a change
+// of 3e-4 in the normal and, through the mirror, into other texels - the reference's image is a
+// chaotic function of those bits, and only the same operations reproduce it.  What a hit's colour is
+// made of is continuous in its inputs and relaxed: texture and lightmap coordinates, light terms,
+// Phong, the soft-shadow ray's own arithmetic, the sums that put a pixel together, the tone map.  There
+// multiplications fuse with additions, roots, reciprocals and quotients come from the hardware's
+// one-ulp instructions, powf is exp2(y * log2(x)), and a pixel always packs from the tone map's
+// estimate.  Frames of the fast tier are not bit-identical to a strict CPU evaluation; they stay
+// within 2/255 per channel with at least 99.9 % of the pixels identical (tests/test_fast_tier_gpu.py).
+//
+// This file is strict by default in both tiers; the relaxed parts stand between RM_FAST_BEGIN and
+// RM_FAST_END and compute with VC, a vector type whose operators may fuse (in the strict tier VC is V3).
+#ifndef RM_FAST
+#define RM_FAST 0
+#endif
+#if RM_FAST
+#pragma clang fp contract(off)
+#define RM_FAST_BEGIN _Pragma("clang fp contract(fast)")
+#define RM_FAST_END _Pragma("clang fp contract(off)")
+#else
+#define RM_FAST_BEGIN
+#define RM_FAST_END
+#endif
+
 // Diagnostic builds (-DRM_DIAG) count march-loop iterations per wave and per lane in LDS; the
 // render kernel adds them to the spare statistics slots 4..6.
 #ifdef RM_DIAG
@@ -128,6 +155,41 @@ RM_DEV V3 refract(V3 v, V3 n, float ior) {
     return v * ior - n * (ior * c + sqrt_rn(k));
 }
 
+// The vector type of the colour arithmetic (see RM_FAST above).
+#if RM_FAST
+RM_FAST_BEGIN
+struct VC {
+    float x, y, z;
+    VC() = default;
+    RM_DEV VC(V3 v) : x(v.x), y(v.y), z(v.z) {}
+    RM_DEV operator V3() const { return V3{x, y, z}; }
+};
+RM_DEV VC vc(float x, float y, float z) {
+    VC r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    return r;
+}
+RM_DEV VC operator+(VC a, VC b) { return vc(a.x + b.x, a.y + b.y, a.z + b.z); }
+RM_DEV VC operator-(VC a, VC b) { return vc(a.x - b.x, a.y - b.y, a.z - b.z); }
+RM_DEV VC operator*(VC a, float s) { return vc(a.x * s, a.y * s, a.z * s); }
+RM_DEV VC operator/(VC a, float s) {
+    const float y = __builtin_amdgcn_rcpf(s);
+    return vc(a.x * y, a.y * y, a.z * y);
+}
+RM_DEV VC operator-(VC a) { return vc(-a.x, -a.y, -a.z); }
+RM_DEV VC emul(VC a, VC b) { return vc(a.x * b.x, a.y * b.y, a.z * b.z); }
+RM_DEV float mag_sqd(VC a) { return (a.x * a.x + a.y * a.y) + a.z * a.z; }
+RM_DEV float dot(VC a, VC b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RM_DEV VC normalized(VC a) { return a * __builtin_amdgcn_rsqf(mag_sqd(a)); }
+RM_DEV VC reflect(VC v, VC n) { return v - n * (2.0f * dot(n, v)); }
+RM_FAST_END
+#else
+typedef V3 VC;
+RM_DEV VC vc(float x, float y, float z) { return V3{x, y, z}; }
+#endif
+
 // Rust f32::clamp keeps a NaN input; f32::min/max drop a NaN operand.
 RM_DEV float rs_clamp(float x, float lo, float hi) {
     if (x < lo) x = lo;
@@ -206,6 +268,9 @@ RM_DEV float sqrt_rn(float x) {
     if (wave_all(sqrt_fast_range(x))) return sqrt_rn_in_range(x);
     return sqrtf(x);
 }
+
+// The root of the colour arithmetic: the hardware's in the fast tier.
+RM_DEV float sqrt_colour(float x) { return RM_FAST ? __builtin_amdgcn_sqrtf(x) : sqrt_rn(x); }
 
 // Correctly rounded division for operands in a known range, with the work on the divisor shared
 // between dividends.  v_rcp_f32 refined by one Newton step is the correctly rounded reciprocal, and
@@ -871,8 +936,13 @@ RM_DEV int march(const SC &sc, V3 &pos, V3 dir, int ignore, int cap, int &steps,
 }
 
 // ray.rs:87-118, same loop shape: finished lanes are frozen by selects.
+// (Fast tier: the ray's own arithmetic - steps, quotient, smoothstep - is relaxed; the distances it
+// evaluates are the march's.  The shade is a continuous function of all of it.)
+RM_FAST_BEGIN
 template <class SC, class IGN>
-RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float light_dist, float k, LaneMask wanted) {
+RM_DEV float shadow_with(const SC &sc, V3 pos_in, V3 dir_in, const IGN &ign, float light_dist, float k, LaneMask wanted) {
+    VC pos = pos_in;
+    const VC dir = dir_in;
     float travelled = 0.0f;
     float shade = 1.0f;
     LaneMask act = lanes_here() & wanted;
@@ -891,7 +961,7 @@ RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float lig
         // stopped: it is never negative in a running lane)
         if (!(a >= travelled) && active) {
             diag_event(4);
-            const float x = rs_clamp(a / travelled, 0.0f, 1.0f);
+            const float x = rs_clamp(RM_FAST ? a * __builtin_amdgcn_rcpf(travelled) : a / travelled, 0.0f, 1.0f);
             const float ss = 3.0f * (x * x) - 2.0f * (x * (x * x));
             sh2 = rs_min(shade, ss);
         }
@@ -904,6 +974,7 @@ RM_DEV float shadow_with(const SC &sc, V3 pos, V3 dir, const IGN &ign, float lig
     }
     return rs_clamp(shade, 0.0f, 1.0f);
 }
+RM_FAST_END
 
 // `wanted` = false in a lane whose caller has no use for the value (it returns 1 there): such lanes
 // do not keep the wave's loop running, and a wave without a wanted lane skips it.
@@ -953,12 +1024,15 @@ RM_DEV V3 calculate_normal(int type, const Geom &g, V3 p, bool tetra) {
     return normalized(grad);
 }
 
+// ---- what a hit's colour is made of: relaxed in the fast tier (see RM_FAST) ----
+RM_FAST_BEGIN
+
 // objects.rs:285-290, 305-310, 325-330, 353-358
-RM_DEV void sample_uv_from_pos(int type, const Geom &g, V3 pos, float ms, float &u, float &v) {
+RM_DEV void sample_uv_from_pos(int type, const Geom &g, VC pos, float ms, float &u, float &v) {
     const float half = ms / 2.0f;
     switch (type) {
         case T_SPHERE: {
-            V3 n = normalized(pos - v3(g.p[0], g.p[1], g.p[2]));
+            VC n = normalized(pos - vc(g.p[0], g.p[1], g.p[2]));
             float uu = 0.5f + atan2f(n.x, -n.z) / 6.28318530717958647692f;
             float vv = 0.5f + (n.y / 2.0f);
             u = uu * ms;
@@ -978,9 +1052,9 @@ RM_DEV void sample_uv_from_pos(int type, const Geom &g, V3 pos, float ms, float 
             v = pos.y + half - 0.5f;
             return;
         default: {  // T_PLANE (no counterpart in the reference, objects.rs:42): p = normal, distance, tangent, sign of the bitangent
-            const V3 n = v3(g.p[0], g.p[1], g.p[2]), t = v3(g.p[4], g.p[5], g.p[6]);
-            const V3 b = v3(n.y * t.z - n.z * t.y, n.z * t.x - n.x * t.z, n.x * t.y - n.y * t.x) * g.p[7];
-            const V3 rel = pos - n * g.p[3];
+            const VC n = vc(g.p[0], g.p[1], g.p[2]), t = vc(g.p[4], g.p[5], g.p[6]);
+            const VC b = vc(n.y * t.z - n.z * t.y, n.z * t.x - n.x * t.z, n.x * t.y - n.y * t.x) * g.p[7];
+            const VC rel = pos - n * g.p[3];
             u = dot(rel, t) + half - 0.5f;
             v = dot(rel, b) + half - 0.5f;
             return;
@@ -1006,7 +1080,7 @@ RM_DEV SceneRef scene_here(SceneRef sv) {
 }
 
 // texture.rs:31-37
-RM_DEV V3 texture_sample(const TextureRec &t, float u, float v) {
+RM_DEV VC texture_sample(const TextureRec &t, float u, float v) {
     float ax = floorf(fabsf(u * t.uscale)), ay = floorf(fabsf(v * t.vscale));
     float fw = (float)t.w, fh = (float)t.h;
     float fx, fy;
@@ -1024,23 +1098,23 @@ RM_DEV V3 texture_sample(const TextureRec &t, float u, float v) {
     x = min(x, t.w - 1);  // fmod keeps both below w/h; NaN maps to 0
     y = min(y, t.h - 1);
     const float *px = t.texels + 4 * (size_t)(x + y * t.w);
-    return v3(px[0], px[1], px[2]);
+    return vc(px[0], px[1], px[2]);
 }
 
 // objects.rs:260, 267-274, 294, 314, 336
-RM_DEV V3 object_colour(SceneRef sv, const ShadeRec &sr, const Geom &g, V3 pos) {
+RM_DEV VC object_colour(SceneRef sv, const ShadeRec &sr, const Geom &g, VC pos) {
     if (sr.textured) {
         float u, v;
         sample_uv_from_pos(T_YPLANE, g, pos, (float)sv.map_size, u, v);
         return texture_sample(sv.tex[sr.texture], u, v);
     }
-    return v3(sr.cr, sr.cg, sr.cb);
+    return vc(sr.cr, sr.cg, sr.cb);
 }
 
 // The four luxels around a sample.  Indices outside the map (the reference aborts on them) are
 // clamped and reported; the check is made once for the four, the clamps only when it fails.
-RM_DEV void luxels4(SceneRef sv, const float *lm, int u0, int u1, int v0, int v1, bool &oob, V3 &s00, V3 &s01,
-                    V3 &s10, V3 &s11) {
+RM_DEV void luxels4(SceneRef sv, const float *lm, int u0, int u1, int v0, int v1, bool &oob, VC &s00, VC &s01,
+                    VC &s10, VC &s11) {
     const int M = sv.map_size;
     const unsigned m = (unsigned)M;
     if (!(((unsigned)u0 < m) & ((unsigned)u1 < m) & ((unsigned)v0 < m) & ((unsigned)v1 < m))) {
@@ -1052,23 +1126,23 @@ RM_DEV void luxels4(SceneRef sv, const float *lm, int u0, int u1, int v0, int v1
     }
     const float *r0 = lm + 3 * (u0 * M), *r1 = lm + 3 * (u1 * M);
     const float *p00 = r0 + 3 * v0, *p01 = r0 + 3 * v1, *p10 = r1 + 3 * v0, *p11 = r1 + 3 * v1;
-    s00 = v3(p00[0], p00[1], p00[2]);
-    s01 = v3(p01[0], p01[1], p01[2]);
-    s10 = v3(p10[0], p10[1], p10[2]);
-    s11 = v3(p11[0], p11[1], p11[2]);
+    s00 = vc(p00[0], p00[1], p00[2]);
+    s01 = vc(p01[0], p01[1], p01[2]);
+    s10 = vc(p10[0], p10[1], p10[2]);
+    s11 = vc(p11[0], p11[1], p11[2]);
 }
 
 // `mag_sqd() == 0.0` (objects.rs:78-113) without the squares: the sum of three squares is zero exactly
 // when each square rounds to zero, which it does up to |x| = 2^-75 (x * x = 2^-150 lies halfway
 // between 0 and the smallest denormal and goes to the even neighbour, 0).  A NaN fails both forms.
-RM_DEV bool no_light(V3 s) {
+RM_DEV bool no_light(VC s) {
     const float t = 0x1p-75f;
     return fabsf(s.x) <= t && fabsf(s.y) <= t && fabsf(s.z) <= t;
 }
 
 // objects.rs:45-133 with colour.rs:47-71 (the two sorts there leave the four
 // corners in the order they are passed in, because u0 < u1 and v0 < v1 always).
-RM_DEV V3 sample_lightmap(SceneRef sv, const ShadeRec &sr, const Geom &g, V3 pos) {
+RM_DEV VC sample_lightmap(SceneRef sv, const ShadeRec &sr, const Geom &g, VC pos) {
     const int M = sv.map_size;
     const float *lm = sv.lightmaps + (size_t)sr.lm_slot * M * M * 3;
     float u, v;
@@ -1083,7 +1157,7 @@ RM_DEV V3 sample_lightmap(SceneRef sv, const ShadeRec &sr, const Geom &g, V3 pos
     v1 = (v1 >= M) ? v0 : v1;
 
     bool oob = false;
-    V3 s00, s01, s10, s11;
+    VC s00, s01, s10, s11;
     luxels4(sv, lm, u0, u1, v0, v1, oob, s00, s01, s10, s11);
 
     bool resample = false;
@@ -1120,7 +1194,7 @@ RM_DEV V3 sample_lightmap(SceneRef sv, const ShadeRec &sr, const Geom &g, V3 pos
 
     // colour.rs:52-70 with (x1,y1)=(u0,v0): q11=s00, q12=s01, q21=s10, q22=s11
     float x1 = (float)u0, x2 = (float)u1, y1 = (float)v0, y2 = (float)v1;
-    V3 acc = (((s00 * (x2 - u)) * (y2 - v)) + ((s10 * (u - x1)) * (y2 - v))) + ((s01 * (x2 - u)) * (v - y1));
+    VC acc = (((s00 * (x2 - u)) * (y2 - v)) + ((s10 * (u - x1)) * (y2 - v))) + ((s01 * (x2 - u)) * (v - y1));
     acc = acc + ((s11 * (u - x1)) * (v - y1));
     // the cell is one luxel wide and high, so the divisor is exactly 1 (x / 1 = x); other values can
     // only come from indices the reference would have aborted on
@@ -1130,8 +1204,8 @@ RM_DEV V3 sample_lightmap(SceneRef sv, const ShadeRec &sr, const Geom &g, V3 pos
 
 // colour.rs:74-98
 // (`li` = intensity / (dist * dist), colour.rs:83, formed by the caller)
-RM_DEV void phong_ds(V3 n, V3 l, float li, const ShadeRec &m, V3 view, float &diffuse, float &specular) {
-    V3 r = reflect(l, n);
+RM_DEV void phong_ds(VC n, VC l, float li, const ShadeRec &m, VC view, float &diffuse, float &specular) {
+    VC r = reflect(l, n);
     diffuse = m.diffuse * li * rs_max(dot(l, n), 0.0f);
     specular = 0.0f;
     if (diffuse > 0.0f) {
@@ -1140,7 +1214,12 @@ RM_DEV void phong_ds(V3 n, V3 l, float li, const ShadeRec &m, V3 view, float &di
         // and positive; only then is the call left out.
         bool zero = (m.specular == 0.0f) && (m.shininess >= 0.0f) && (li > 0.0f) && (li < __builtin_inff()) &&
                     (base < __builtin_inff());
-        if (!zero) specular = m.specular * li * powf(base, m.shininess);
+        if (!zero) {
+            // (fast tier: exp2(y * log2(x)) from the hardware's one-ulp functions; 0^0 = 1 as powf has it)
+            const float p = RM_FAST ? (m.shininess == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(m.shininess * __builtin_amdgcn_logf(base)))
+                                    : powf(base, m.shininess);
+            specular = m.specular * li * p;
+        }
     }
 }
 
@@ -1149,8 +1228,15 @@ RM_DEV void phong_ds(V3 n, V3 l, float li, const ShadeRec &m, V3 view, float &di
 // (distances between 2^-20 and 2^20, a light intensity between 2^-40 and 2^40, no vector component
 // below 2^-90 other than zero) shares the work on each divisor; any other wave takes the compiler's
 // IEEE divisions.  Both deliver the same correctly rounded values.
-RM_DEV void light_terms(V3 &to_light, float intensity, float &dist, float &li) {
+RM_DEV void light_terms(VC &to_light, float intensity, float &dist, float &li) {
     const float m = mag_sqd(to_light);
+    if (RM_FAST) {
+        const float y = __builtin_amdgcn_rsqf(m);
+        dist = m * y;
+        to_light = to_light * y;
+        li = intensity * (y * y);
+        return;
+    }
     // (bitwise on purpose: three cheap tests, no short-circuit branches)
     const bool usual = (int)float_bits_within(m, 0x2B800000, 0x53800000) &            // 2^-40 <= m < 2^40
                        (int)float_bits_within(intensity, 0x2B800000, 0x53800000) &    // (the same in every lane)
@@ -1158,7 +1244,7 @@ RM_DEV void light_terms(V3 &to_light, float intensity, float &dist, float &li) {
     if (wave_all(usual)) {
         dist = sqrt_rn_in_range(m);
         const float y = recip_rn_in_range(dist);
-        to_light = v3(div_rn_in_range(to_light.x, dist, y), div_rn_in_range(to_light.y, dist, y), div_rn_in_range(to_light.z, dist, y));
+        to_light = vc(div_rn_in_range(to_light.x, dist, y), div_rn_in_range(to_light.y, dist, y), div_rn_in_range(to_light.z, dist, y));
         const float d2 = dist * dist;
         li = div_rn_in_range(intensity, d2, recip_rn_in_range(d2));
     } else {
@@ -1169,9 +1255,9 @@ RM_DEV void light_terms(V3 &to_light, float intensity, float &dist, float &li) {
 }
 
 struct ShadeResult {
-    V3 final_colour;  // engine.rs:194
-    V3 object_colour;
-    V3 n;
+    VC final_colour;  // engine.rs:194
+    VC object_colour;
+    V3 n;  // (strict in both tiers: the mirror ray is built from it)
     float reflectivity;
 };
 
@@ -1182,10 +1268,10 @@ RM_DEV ShadeResult shade_local(const SC &sc, SceneRef sv_of_kernel, int idx, V3 
     const ShadeRec sr = sv.shade[idx];
     const Geom g = sv.geom[idx];
     ShadeResult out;
-    V3 oc = (RM_ABL & 64) ? v3(sr.cr, sr.cg, sr.cb) : object_colour(sv, sr, g, pos);
+    VC oc = (RM_ABL & 64) ? vc(sr.cr, sr.cg, sr.cb) : object_colour(sv, sr, g, pos);
     V3 n = (RM_ABL & 32) ? v3(0.0f, 1.0f, 0.0f) : calculate_normal(sr.type, g, pos, sv.tetra_normals != 0);
 
-    V3 ambient;
+    VC ambient;
     if ((RM_ABL & 4) || sr.lm_slot < 0)
         ambient = oc * sr.ambient;  // engine.rs:158
     else
@@ -1193,8 +1279,8 @@ RM_DEV ShadeResult shade_local(const SC &sc, SceneRef sv_of_kernel, int idx, V3 
     if (mag_sqd(ambient) < sr.ambient * sr.ambient) ambient = normalized(ambient) * sr.ambient;  // engine.rs:163-165
     ambient = emul(ambient, oc);                                                                  // engine.rs:168
 
-    V3 light = v3(sv.light[0], sv.light[1], sv.light[2]);
-    V3 to_light = light - pos;
+    VC light = vc(sv.light[0], sv.light[1], sv.light[2]);
+    VC to_light = light - VC(pos);
     float dist, li;
     light_terms(to_light, sv.intensity, dist, li);
 
@@ -1228,7 +1314,7 @@ RM_DEV V3 cast_sight_ray(const SC &sc, SceneRef sv, V3 pos, V3 dir, float first 
     // and the frame 2 % slower; the traffic costs no time at 0.2 TB/s.)
     float stk[MAX_DEPTH][7];
     int depth = 0;
-    V3 colour;
+    VC colour;
     for (;;) {
         int steps;
         bool capped;
@@ -1238,11 +1324,11 @@ RM_DEV V3 cast_sight_ray(const SC &sc, SceneRef sv, V3 pos, V3 dir, float first 
         first = __builtin_nanf("");  // known for the ray from the camera only
         if (capped) atomicAdd(&sv.stats[1], 1ULL);
         if (idx < 0) {
-            colour = v3(sv.sky[0], sv.sky[1], sv.sky[2]);
+            colour = vc(sv.sky[0], sv.sky[1], sv.sky[2]);
             break;
         }
         if (RM_ABL & 8) {
-            colour = v3(pos.x * 0.1f + 0.5f, pos.y * 0.1f + 0.5f, (float)idx * 0.1f);
+            colour = vc(pos.x * 0.1f + 0.5f, pos.y * 0.1f + 0.5f, (float)idx * 0.1f);
             break;
         }
         ShadeResult r = shade_local(sc, sv, idx, pos, dir);
@@ -1272,12 +1358,13 @@ RM_DEV V3 cast_sight_ray(const SC &sc, SceneRef sv, V3 pos, V3 dir, float first 
     }
     while (depth > 0) {
         depth--;
-        V3 f = v3(stk[depth][0], stk[depth][1], stk[depth][2]);
-        V3 oc = v3(stk[depth][3], stk[depth][4], stk[depth][5]);
+        VC f = vc(stk[depth][0], stk[depth][1], stk[depth][2]);
+        VC oc = vc(stk[depth][3], stk[depth][4], stk[depth][5]);
         colour = f + emul(colour, oc) * stk[depth][6];  // engine.rs:239-240
     }
     return colour;
 }
+RM_FAST_END
 
 // ray.rs:44-56: walks a ray that starts inside an object to where it leaves it, by the object's own
 // distance alone, 20 steps at most.
@@ -1415,23 +1502,28 @@ RM_DEV unsigned pack_pixel_exact(V3 c) {
 // One channel of the same through the hardware's one-ulp reciprocal and square root: y estimates
 // 255 * sqrt(ACES(x)) to within 7e-5 (three roundings and two one-ulp functions on a value of at most
 // 260), and so does the value the exact operations produce.  Where y is a finite non-negative number
-// at least 2e-4 away from every k + 1/2, both round to the same byte; `sure` says so.
-RM_DEV unsigned channel_estimate(float x, bool &sure) {
+// (`sane`) at least 2e-4 away from every k + 1/2 (`sure`), both round to the same byte.
+RM_FAST_BEGIN
+RM_DEV unsigned channel_estimate(float x, bool &sure, bool &sane) {
     const float num = x * (2.51f * x + 0.03f), den = x * (2.43f * x + 0.59f) + 0.14f;
     const float y = 255.0f * __builtin_amdgcn_sqrtf(num * __builtin_amdgcn_rcpf(den));
     const float fl = floorf(y), fr = y - fl;
-    sure = sure && y >= 0.0f && y < 1e6f && fabsf(fr - 0.5f) > 2e-4f;
+    sane = sane && y >= 0.0f && y < 1e6f;
+    sure = sure && fabsf(fr - 0.5f) > 2e-4f;
     const float rounded = fl + (fr > 0.5f ? 1.0f : 0.0f);
     return (unsigned)fminf(rounded, 255.0f);
 }
 
-RM_DEV unsigned pack_pixel(V3 linear, float exposure) {
-    V3 c = linear * exposure;
+RM_DEV unsigned pack_pixel(VC linear, float exposure) {
+    VC c = linear * exposure;
     if (RM_ABL & 16) return to_pixel_range(c.x) | (to_pixel_range(c.y) << 8) | (to_pixel_range(c.z) << 16);
-    bool sure = true;
-    const unsigned r = channel_estimate(c.x, sure), g = channel_estimate(c.y, sure), b = channel_estimate(c.z, sure);
-    if (wave_all(sure)) return b | (g << 8) | (r << 16);
+    bool sure = true, sane = true;
+    const unsigned r = channel_estimate(c.x, sure, sane), g = channel_estimate(c.y, sure, sane), b = channel_estimate(c.z, sure, sane);
+    // (fast tier: the estimate alone - a value within 2e-4 of a rounding boundary may land on the other
+    // byte - unless something in the wave is negative or not a number)
+    if (wave_all(RM_FAST ? sane : (sure && sane))) return b | (g << 8) | (r << 16);
     return pack_pixel_exact(c);  // a lane close to a rounding boundary, or not a number: the whole wave takes the exact operations
 }
+RM_FAST_END
 
 }  // namespace rm

@@ -272,6 +272,12 @@ class Engine:
         only for emission values that are not finite; see rm.h)."""
         _lib.check(self.lib.rm_engine_set_exact_occlusion(self.handle, 1 if on else 0), "rm_engine_set_exact_occlusion")
 
+    def set_precision(self, precision):
+        """'strict' (default: the reference's operations, bit for bit) or 'fast' (the sight-ray chain strict,
+        the colour arithmetic relaxed; within 2/255 and 99.9 % identical pixels; see rm.h)."""
+        code = {"strict": _lib.RM_PRECISION_STRICT, "fast": _lib.RM_PRECISION_FAST}[precision]
+        _lib.check(self.lib.rm_engine_set_precision(self.handle, code), "rm_engine_set_precision")
+
     def set_march_cap(self, max_steps):
         _lib.check(self.lib.rm_engine_set_march_cap(self.handle, max_steps), "rm_engine_set_march_cap")
 
