@@ -40,6 +40,9 @@ namespace rm {
 #ifndef RM_FAST
 #define RM_FAST 0
 #endif
+#ifndef RM_FAST_PRIMARY
+#define RM_FAST_PRIMARY 0
+#endif
 #if RM_FAST
 #pragma clang fp contract(off)
 #define RM_FAST_BEGIN _Pragma("clang fp contract(fast)")
@@ -490,46 +493,6 @@ RM_DEV SphereBound make_bound(const SC &sc, V3 o, V3 dir, float tmax) {
     return b;
 }
 
-// Box distance (extension, objects.rs:370-380 with centre c and half extents h).
-RM_DEV float box_sdf(V3 c, V3 h, V3 p) {
-    V3 q = v3(fabsf(p.x - c.x) - h.x, fabsf(p.y - c.y) - h.y, fabsf(p.z - c.z) - h.z);
-    V3 r = v3(rs_max(q.x, 0.0f), rs_max(q.y, 0.0f), rs_max(q.z, 0.0f));
-    return sqrt_rn(mag_sqd(r)) + rs_min(rs_max(q.x, rs_max(q.y, q.z)), 0.0f);
-}
-
-// Spatial index lookup for a point: the list ranges of its cell, empty for a point outside the
-// grid (or a NaN).
-struct CellLists {
-    int s_at, ns, b_at, nb;  // where the blocks start in the pool, and their entry counts
-    float reach;             // every primitive outside the lists is at least this far from p
-};
-RM_DEV CellLists grid_cell(const GridView &gv, int level, V3 p) {
-    const float fx = (p.x - gv.ox) * gv.inv_cell, fy = (p.y - gv.oy) * gv.inv_cell, fz = (p.z - gv.oz) * gv.inv_cell;
-    const bool inside = fx >= 0.0f && fx < (float)gv.nx && fy >= 0.0f && fy < (float)gv.ny && fz >= 0.0f && fz < (float)gv.nz;
-    CellLists c = {0, 0, 0, 0, gv.reach};
-    const int cell = inside ? ((int)fz * gv.ny + (int)fy) * gv.nx + (int)fx : -1;  // non-negative: truncation is floor
-    const int ucell = __builtin_amdgcn_readfirstlane(cell);
-    const ConstInt4s table = (ConstInt4s)gv.pool + (size_t)level * gv.cells;
-    if (ucell >= 0 && wave_all(cell == ucell)) {
-        // every lane in the same cell (the usual case for a tile): its record comes by a scalar load
-        const Int4 rec = table[ucell];
-        c.s_at = rec.x;
-        c.ns = rec.z & 0xffff;
-        c.b_at = rec.y;
-        c.nb = (unsigned)rec.z >> 16;
-        c.reach = __int_as_float(rec.w);
-        return c;
-    }
-    if (inside) {
-        const Int4 rec = table[cell];
-        c.s_at = rec.x;
-        c.ns = rec.z & 0xffff;
-        c.b_at = rec.y;
-        c.nb = (unsigned)rec.z >> 16;
-        c.reach = __int_as_float(rec.w);
-    }
-    return c;
-}
 // One sphere (box) of a block, fetched by a lane of its own.
 struct SphereEntry {
     Float4 g;
@@ -553,55 +516,6 @@ RM_DEV BoxEntry grid_box(const GridView &gv, int b_at, int j) {
     return e;
 }
 
-// The state of one fold over a cell's lists, kept in plain values (not captured by reference in
-// closures: the compiler then keeps it in registers instead of private memory).
-struct FoldState {
-    float r;             // the running value
-    float reach;         // r + k (hard minimum: r): a primitive at least this far away changes nothing
-    float floor_before;  // minimum of everything folded so far and of the cell's reach (blend only)
-    bool certain;        // blend only: the value is known to equal the full fold
-};
-RM_DEV FoldState fold_in(FoldState st, float s, float k, float slack, bool blend) {
-    if (blend) {
-        if (s + slack <= st.floor_before) {
-            st.r = s;
-            st.certain = true;
-        } else {
-            st.r = smooth_min(st.r, s, k);
-        }
-        st.floor_before = rs_min(st.floor_before, s);
-        st.reach = st.r + k;
-    } else {
-        st.r = rs_min(st.r, s);
-        st.reach = st.r;
-    }
-    return st;
-}
-// A primitive at least k beyond the running value (hard minimum: at or beyond it) changes nothing:
-// the smooth minimum returns the running value, which is never more than k above floor_before, so
-// neither of the other two lines of fold_in acts either.  For a sphere the squared centre distance
-// decides that for most entries, without a square root; for a box, its distance outside is at least
-// the largest of its three face distances.  The test is what most list entries cost, so it is kept
-// short: its squared distance comes from fused multiply-adds (the exact one, in the reference's order
-// of operations, is formed only for an entry that passes).
-template <class IGN>
-RM_DEV FoldState fold_sphere(FoldState st, const IGN &ign, V3 p, float cx, float cy, float cz, float rad, int oi, float k, float slack,
-                             bool blend) {
-    const V3 d = p - v3(cx, cy, cz);
-    const float m_est = __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x));  // within 2e-7 of the exact sum, relatively
-    // centre distance beyond reach + radius, compared in squares: the exact square is within 4e-7 of
-    // the true one, the rounded root within 6e-8 of the true root, the margin is 1e-5
-    const float beyond = __builtin_fmaf(rs_max(st.reach + rad, 0.0f), 1.00001f, 1e-6f);
-    if (!(m_est > beyond * beyond) && !ign.skip(oi)) st = fold_in(st, ign.mask(oi, sqrt_rn(mag_sqd(d)) - rad), k, slack, blend);
-    return st;
-}
-template <class IGN>
-RM_DEV FoldState fold_box(FoldState st, const IGN &ign, V3 p, V3 bc, V3 bh, int oi, float k, float slack, bool blend) {
-    const float face = rs_max(fabsf(p.x - bc.x) - bh.x, rs_max(fabsf(p.y - bc.y) - bh.y, fabsf(p.z - bc.z) - bh.z));
-    if (!(face > __builtin_fmaf(2e-6f, face, st.reach + 1e-6f)) && !ign.skip(oi)) st = fold_in(st, ign.mask(oi, box_sdf(bc, bh, p)), k, slack, blend);
-    return st;
-}
-
 typedef float Float16 __attribute__((ext_vector_type(16)));
 // (scalar loads need dword alignment only; the element type says so, lest a wider alignment be assumed)
 typedef Float16 __attribute__((aligned(4))) Float16u;
@@ -609,384 +523,37 @@ typedef Int4 __attribute__((aligned(4))) Int4u;
 typedef const __attribute__((address_space(4))) Float16u *ConstFloat16s;
 typedef const __attribute__((address_space(4))) Int4u *ConstInt4us;
 
-// The sphere and box part of the fold below, done over the lists of p's grid cell only.  Returns
-// whether the value is certain to equal the fold over every sphere and box; `r` enters as the value
-// after the planes and leaves as the result.
-//
-// Every primitive missing from the lists is at least R = reach away.
-//   * Hard minimum: if the minimum over planes and listed primitives is <= R, no missing one can
-//     lower it.
-//   * Smooth minimum, folded in order: a missing primitive is a no-op whenever the running value is
-//     <= R - k at its turn, and the running value never rises.  That holds from the start if the
-//     planes already bring it there.  Otherwise the fold over the listed primitives may differ from
-//     the full one until a listed primitive with distance s arrives that lies 2k below everything
-//     folded before it (planes, listed ones, and R for the missing ones): a running value is never
-//     more than k below the minimum of what was folded, so at that turn the gap is >= k in both
-//     folds, both take exactly s (<= R - 2k), and from there on they agree.  (`slack` keeps the
-//     comparison clear of the rounding of the two sums.)
-template <class SC, class IGN>
-RM_DEV bool grid_fold(const SC &sc, int level, V3 p, const IGN &ign, float &r_io, float k, bool blend) {
-    const GridView &gv = sc.grid();
-    const CellLists c = grid_cell(gv, level, p);
-    const float R = c.reach;
-    const float slack = 2.01f * k + 1e-4f;
-    FoldState st;
-    st.r = r_io;
-    st.reach = blend ? r_io + k : r_io;
-    st.certain = r_io <= R - k;  // blend only
-    st.floor_before = rs_min(r_io, R);
-    // The pixels of a tile mostly sit in one cell.  A wave whose lanes all do walks the lists with
-    // wave-uniform indices: the entries arrive by scalar loads, once per wave, and no lane waits for
-    // another's longer list.  Four spheres (two boxes) come with one 64-byte load, so that the wave
-    // waits for memory once per group and not once per entry.
-    const int us_at = __builtin_amdgcn_readfirstlane(c.s_at), uns = __builtin_amdgcn_readfirstlane(c.ns);
-    const int ub_at = __builtin_amdgcn_readfirstlane(c.b_at), unb = __builtin_amdgcn_readfirstlane(c.nb);
-    if (wave_all(c.s_at == us_at && c.ns == uns && c.b_at == ub_at && c.nb == unb)) {
-        ConstInts group = constant(gv.pool) + us_at;
-        for (int e = 0; e < uns; e += 4, group += kGridSphereGroup) {
-            const Float16 g = *(ConstFloat16s)group;
-            const Int4 oi = *(ConstInt4us)(group + 16);
-            st = fold_sphere(st, ign, p, g.s0, g.s1, g.s2, g.s3, oi.x, k, slack, blend);
-            if (e + 1 < uns) st = fold_sphere(st, ign, p, g.s4, g.s5, g.s6, g.s7, oi.y, k, slack, blend);
-            if (e + 2 < uns) st = fold_sphere(st, ign, p, g.s8, g.s9, g.sa, g.sb, oi.z, k, slack, blend);
-            if (e + 3 < uns) st = fold_sphere(st, ign, p, g.sc, g.sd, g.se, g.sf, oi.w, k, slack, blend);
-        }
-        ConstInts pair = constant(gv.pool) + ub_at;
-        for (int e = 0; e < unb; e += 2, pair += 16) {
-            const Float16 g = *(ConstFloat16s)pair;
-            st = fold_box(st, ign, p, v3(g.s0, g.s1, g.s2), v3(g.s3, g.s4, g.s5), __float_as_int(g.s6), k, slack, blend);
-            if (e + 1 < unb) st = fold_box(st, ign, p, v3(g.s8, g.s9, g.sa), v3(g.sb, g.sc, g.sd), __float_as_int(g.se), k, slack, blend);
-        }
-        r_io = st.r;
-        return blend ? st.certain : (st.r <= R);
-    }
-    // Otherwise every lane walks its own lists.  Entries are fetched four (boxes: two) at a time
-    // before any is used, so that a list costs one memory round trip per group instead of one per
-    // entry; they are folded one by one, in order.
-    for (int e = 0; e < c.ns; e += 4) {
-        SphereEntry s[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) s[u] = grid_sphere(gv, c.s_at, min(e + u, c.ns - 1));
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (e + u < c.ns) st = fold_sphere(st, ign, p, s[u].g.x, s[u].g.y, s[u].g.z, s[u].g.w, s[u].oi, k, slack, blend);
-    }
-    for (int e = 0; e < c.nb; e += 2) {
-        BoxEntry b[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) b[u] = grid_box(gv, c.b_at, min(e + u, c.nb - 1));
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-            if (e + u < c.nb)
-                st = fold_box(st, ign, p, v3(b[u].g0.x, b[u].g0.y, b[u].g0.z), v3(b[u].g0.w, b[u].g1.x, b[u].g1.y), __float_as_int(b[u].g1.z), k, slack,
-                              blend);
-    }
-    r_io = st.r;
-    return blend ? st.certain : (st.r <= R);
+// The march family: strict here, and once more with relaxed arithmetic for the fast tier.
+constexpr bool kRelaxedMarch = false;
+#include "rm_march.inc"
+#if RM_FAST
+RM_FAST_BEGIN
+namespace relaxed {
+typedef VC V3;  // (inside this namespace the march family computes with the vector type whose operators may fuse)
+RM_DEV VC v3(float x, float y, float z) { return vc(x, y, z); }
+RM_DEV float sqrt_rn(float x) { return __builtin_amdgcn_sqrtf(x); }
+RM_DEV float smooth_min(float a, float b, float k) {
+    const float gap = fabsf(a - b);
+    if (gap >= k) return rs_min(a, b);
+    const float h = rs_max(k - gap, 0.0f) * __builtin_amdgcn_rcpf(k);
+    return rs_min(a, b) - h * h * k * (1.0f / 4.0f);
 }
-
-// The value `distance` holds after the object loop of ray.rs:23-33 / 98-107: the minimum over
-// objects of sdf(p) - or, with a smooth union (extension), their smooth-minimum fold in group
-// order.
-//
-// `active` marks the lanes whose result is used: a finished lane must not pull the rest of its
-// wave into the sphere evaluation.
-template <class SC, class IGN>
-RM_DEV float scene_min(const SC &sc, V3 p, const IGN &ign, LaneMask act, SphereBound &sb, float travelled) {
-    const bool active = lanes_in(act);
-    const float k = sc.smooth_k();
-    const bool blend = SC::kSmooth && k > 0.0f;  // wave-uniform
-    float d = __builtin_inff();
-    auto fold = [&](float s) {
-        if (blend)
-            d = smooth_min(d, s, k);
-        else
-            d = rs_min(d, s);
-    };
-    // objects.rs:275,295,315: dir * (p - off).  With dir = +-1 the product is exact, so the value is
-    // the rounded +-(p - off), which one fused multiply-add of (dir, p, -dir*off) also delivers:
-    // its addend is exact and loop-invariant.  (Only the sign of a zero result can differ, and the
-    // value feeds nothing but minimum and comparisons.)
-    auto axis_sdf = [&](float pc, float off, float dir) {
-        if constexpr (SC::kUnitAxis)
-            return __builtin_fmaf(dir, pc, -(dir * off));
-        else
-            return dir * (pc - off);
-    };
-    sc.all_planes(
-        [&](int oi, float off, float dir) {
-            if (!ign.skip(oi)) fold(ign.mask(oi, axis_sdf(p.x, off, dir)));
-        },
-        [&](int oi, float off, float dir) {
-            if (!ign.skip(oi)) fold(ign.mask(oi, axis_sdf(p.y, off, dir)));
-        },
-        [&](int oi, float off, float dir) {
-            if (!ign.skip(oi)) fold(ign.mask(oi, axis_sdf(p.z, off, dir)));
-        },
-        [&](int oi, float nx, float ny, float nz, float dist) {
-            if (!ign.skip(oi)) fold(ign.mask(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist));
-        });
-    if constexpr (SC::kGrid) {
-        if (sc.grid().cells > 0) {
-            if (!active) return d;
-            // the cell's short lists first, its long lists if those leave the value open, and the
-            // full walk below if these do too
-            // (one copy of the fold in the code, run for one level after the other)
-            diag_event(6);
-#pragma nounroll
-            for (int level = 0; level < kGridLevels; level++) {
-                float r = d;
-                if (level > 0) diag_event(0);  // the short lists left the value open
-                if (grid_fold(sc, level, p, ign, r, k, blend)) return r;
-            }
-            diag_event(7);
-        }
-    }
-    // spheres: the whole group is skipped while the carried bound proves it irrelevant (with a
-    // smooth union a sphere matters only within k of the running value)
-    const float reach = __builtin_fmaf(travelled, sb.dn, blend ? d + k : d);
-    const LaneMask within = __builtin_amdgcn_fcmpf(reach, sb.T, 5);  // ordered reach <= T: the spheres stay out
-    sb.spheres_out = (sb.spheres_out & ~act) | (act & within);
-    if (lanes_in(act & ~within)) {
-        diag_event(3);
-        // The bound only needs each distance to within a few ulp: the hardware square root (one
-        // ulp) serves.  The correctly rounded value is computed only for a sphere that comes
-        // within sb.eps of deciding the result; eps exceeds the gap between the two values.
-        const float decide = (blend ? d + k : d) + sb.eps;
-        float nearest = __builtin_inff();
-        sc.spheres([&](int, int oi, float cx, float cy, float cz, float r) {
-            if (ign.skip(oi)) return;
-            const float m = mag_sqd(p - v3(cx, cy, cz));
-            const float rough = ign.mask(oi, __builtin_amdgcn_sqrtf(m) - r);
-            nearest = rs_min(nearest, rough);
-            if (!(rough > decide)) {
-                const float exact = ign.mask(oi, sqrt_rn(m) - r);
-                if (blend)
-                    d = smooth_min(d, exact, k);
-                else
-                    d = rs_min_bare(d, exact);
-            }
-        });
-        sb.T = __builtin_fmaf(travelled, sb.dn, nearest - sb.M);
-    }
-    sc.boxes([&](int oi, V3 c, V3 h) {
-        if (ign.skip(oi)) return;
-        // a box whose largest face distance lies k beyond the running value (hard minimum: beyond
-        // it) cannot change the result: its distance is at least that, the margin covers its root
-        const float face = rs_max(fabsf(p.x - c.x) - h.x, rs_max(fabsf(p.y - c.y) - h.y, fabsf(p.z - c.z) - h.z));
-        if (!(face > (blend ? d + k : d) + 2e-6f * face + 1e-6f)) fold(ign.mask(oi, box_sdf(c, h, p)));
-    });
-    return d;
-}
-
-// The hit object: smallest own distance, lowest index on ties (the strict `<` of ray.rs:29);
-// every object is evaluated exactly here.
-template <class SC, class IGN>
-RM_DEV int closest_index(const SC &sc, V3 p, float, const IGN &ign, bool spheres_out = false) {
-    float best = __builtin_inff();
-    int bi = 0x7fffffff;
-    auto take = [&](int oi, float s0) {
-        const float s = ign.mask(oi, s0);
-        // (selects instead of a branch: bitwise operators keep the compiler from short-circuiting)
-        const bool better = (s < best) | ((s == best) & (oi < bi));
-        best = better ? s : best;
-        bi = better ? oi : bi;
-    };
-    sc.all_planes(
-        [&](int oi, float off, float dir) {
-            if (!ign.skip(oi)) take(oi, dir * (p.x - off));
-        },
-        [&](int oi, float off, float dir) {
-            if (!ign.skip(oi)) take(oi, dir * (p.y - off));
-        },
-        [&](int oi, float off, float dir) {
-            if (!ign.skip(oi)) take(oi, dir * (p.z - off));
-        },
-        [&](int oi, float nx, float ny, float nz, float dist) {
-            if (!ign.skip(oi)) take(oi, ((p.x * nx + p.y * ny) + p.z * nz) - dist);
-        });
-    if constexpr (SC::kGrid) {
-        if (sc.grid().cells > 0) {
-            // the primitives missing from a cell's lists are at least its reach away: a best
-            // distance below that cannot be theirs (re-taking a primitive changes nothing)
-            const GridView &gv = sc.grid();
-            auto take_lists = [&](int level) {
-                const CellLists c = grid_cell(gv, level, p);
-                for (int e = 0; e < c.ns; e++) {
-                    const SphereEntry s = grid_sphere(gv, c.s_at, e);
-                    if (!ign.skip(s.oi)) take(s.oi, sqrt_rn(mag_sqd(p - v3(s.g.x, s.g.y, s.g.z))) - s.g.w);
-                }
-                for (int e = 0; e < c.nb; e++) {
-                    const BoxEntry b = grid_box(gv, c.b_at, e);
-                    const int oi = __float_as_int(b.g1.z);
-                    if (!ign.skip(oi)) take(oi, box_sdf(v3(b.g0.x, b.g0.y, b.g0.z), v3(b.g0.w, b.g1.x, b.g1.y), p));
-                }
-                return c.reach;
-            };
-            if (best < take_lists(0)) return bi;
-            if (best < take_lists(1)) return bi;
-        }
-    }
-    if (!(spheres_out && !SC::kGrid))  // (with a spatial index the bound is not kept up on every step)
-        sc.spheres([&](int, int oi, float cx, float cy, float cz, float r) {
-            if (!ign.skip(oi)) take(oi, sqrt_rn(mag_sqd(p - v3(cx, cy, cz))) - r);
-        });
-    sc.boxes([&](int oi, V3 c, V3 h) {
-        if (!ign.skip(oi)) take(oi, box_sdf(c, h, p));
-    });
-    return (bi == 0x7fffffff || !(best < __builtin_inff())) ? -1 : bi;
-}
-
-// ray.rs:15-42 (and ray.rs:58-85: every object type collides, objects.rs:220,343).
-// Returns the hit object or -1; `pos` ends where the reference leaves Ray::position.
-template <class SC, class IGN>
-RM_DEV int march_capped(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, int &steps, bool &capped) {
-    float travelled = 0.0f;
-    float d = 0.0f;
-    bool hit = false;
-    steps = 0;
-    capped = false;
-    SphereBound sb = make_bound(sc, pos, dir, MAX_MARCH_DISTANCE);
-    while (travelled < MAX_MARCH_DISTANCE) {
-        if (steps >= cap) {
-            capped = true;
-            return -1;
-        }
-        steps++;
-        d = scene_min(sc, pos, ign, lanes_here(), sb, travelled);
-        if (d < SMALL_DISTANCE) {
-            hit = true;
-            break;
-        }
-        travelled += d;
-        pos = pos + dir * d;
-    }
-    // Lanes leave the loop above at different times, so the wave-wide mask sb.spheres_out holds, for a
-    // lane, whatever the lanes still running wrote after it left: it is not consulted here, and every
-    // object is evaluated for the hit.
-    return hit ? closest_index(sc, pos, d, ign, false) : -1;
-}
-
-// The same loop for the usual case of no iteration cap, written so that the wave
-// runs it with one scalar back-edge: lanes that have finished are frozen by
-// selects instead of being peeled off through execution-mask bookkeeping.
-// `first` (the same in every lane) is the loop's first distance evaluation where the caller has
-// made it already: the distance from `pos` to the nearest object, at least SMALL_DISTANCE and below
-// MAX_MARCH_DISTANCE, and `first_sph` the distance to the nearest sphere.  NaN = not known.
-template <class SC, class IGN>
-RM_DEV int march_with(const SC &sc, V3 &pos, V3 dir, const IGN &ign, int cap, int &steps, bool &capped, float first,
-                      float first_sph) {
-    // The loop below freezes a stopped lane by steps of dir * 0, which needs a finite direction; a
-    // wave holding a direction that is not (a normal taken where the surface has no gradient left)
-    // takes the plain loop, as does a march with an iteration cap.
-    if (cap > 0 || !wave_all(fabsf(dir.x) + fabsf(dir.y) + fabsf(dir.z) < __builtin_inff()))
-        return march_capped(sc, pos, dir, ign, cap > 0 ? cap : 0x7fffffff, steps, capped);
-    capped = false;
-    steps = 0;
-    float travelled = 0.0f;
-    LaneMask act = lanes_here();  // travelled = 0 < MAX_MARCH_DISTANCE
-    LaneMask hit_lanes = 0;
-    SphereBound sb = make_bound(sc, pos, dir, MAX_MARCH_DISTANCE);
-    if (first == first) {
-        // the first turn of the loop below with its distance given: no hit, the step taken
-        steps = 1;
-        travelled = first;
-        pos = pos + dir * first;
-        sb.T = first_sph - sb.M;  // the carried bound as the evaluation at travelled = 0 would have left it
-    }
-    do {
-        const bool active = lanes_in(act);
-        diag_iter(active, 1);
-        const float d = scene_min(sc, pos, ign, act, sb, travelled);
-        const LaneMask near = lanes_lt(d, SMALL_DISTANCE);
-        hit_lanes |= act & near;
-        const LaneMask go_lanes = act & ~near;
-        const bool go = lanes_in(go_lanes);
-        steps += active ? 1 : 0;
-        const float t2 = travelled + d;
-        travelled = t2;  // (read by running lanes only)
-        // a lane that has stopped takes a step of length 0: dir * 0 is a zero with the sign of dir,
-        // which leaves every coordinate as it is (a coordinate of -0 can only have come from a
-        // direction component of -0, whose zero step is -0 as well)
-        pos = pos + dir * (go ? d : 0.0f);
-        act = go_lanes & lanes_lt(t2, MAX_MARCH_DISTANCE);
-    } while (act != 0);
-    const bool hit = lanes_in(hit_lanes);
-    const float d_hit = 0.0f;
-    diag_lap(DG_MARCH_LOOP);
-    const int idx = hit ? closest_index(sc, pos, d_hit, ign, lanes_in(sb.spheres_out)) : -1;
-    diag_lap(DG_CLOSEST);
+constexpr bool kRelaxedMarch = true;
+#include "rm_march.inc"
+// (the callers hold rm::V3 positions)
+template <class SC>
+RM_DEV int march(const SC &sc, rm::V3 &pos, rm::V3 dir, int ignore, int cap, int &steps, bool &capped, float first = __builtin_nanf(""),
+                 float first_sph = __builtin_nanf("")) {
+    VC p = pos;
+    const int idx = march(sc, p, VC(dir), ignore, cap, steps, capped, first, first_sph);
+    pos = p;
     return idx;
 }
-
-// `ignore` < 0 means None.  A wave whose lanes all leave out the same object
-// (the usual case: neighbouring pixels hit the same surface) takes the variant
-// that drops it by a scalar branch.
-template <class SC>
-RM_DEV int march(const SC &sc, V3 &pos, V3 dir, int ignore, int cap, int &steps, bool &capped,
-                 float first = __builtin_nanf(""), float first_sph = __builtin_nanf("")) {
-    // (the large layout keeps one copy of the loops: its code would not fit the instruction cache threefold)
-    if constexpr (SC::kGrid) return march_with(sc, pos, dir, LaneIgnore{ignore}, cap, steps, capped, first, first_sph);
-    const int u = __builtin_amdgcn_readfirstlane(ignore);
-    if (wave_all(ignore == u)) {
-        if (u < 0) return march_with(sc, pos, dir, NoIgnore{}, cap, steps, capped, first, first_sph);
-        return march_with(sc, pos, dir, UniformIgnore{u}, cap, steps, capped, __builtin_nanf(""), 0.0f);
-    }
-    return march_with(sc, pos, dir, LaneIgnore{ignore}, cap, steps, capped, __builtin_nanf(""), 0.0f);
-}
-
-// ray.rs:87-118, same loop shape: finished lanes are frozen by selects.
-// (Fast tier: the ray's own arithmetic - steps, quotient, smoothstep - is relaxed; the distances it
-// evaluates are the march's.  The shade is a continuous function of all of it.)
-RM_FAST_BEGIN
-template <class SC, class IGN>
-RM_DEV float shadow_with(const SC &sc, V3 pos_in, V3 dir_in, const IGN &ign, float light_dist, float k, LaneMask wanted) {
-    VC pos = pos_in;
-    const VC dir = dir_in;
-    float travelled = 0.0f;
-    float shade = 1.0f;
-    LaneMask act = lanes_here() & wanted;
-    SphereBound sb = make_bound(sc, pos, dir, light_dist);
-    for (int it = 0; it < MAX_SHAD_IT; it++) {
-        const bool active = lanes_in(act);
-        diag_iter(active, 2);
-        const float d = scene_min(sc, pos, ign, act, sb, travelled);
-        // shade = min(shade, smoothstep(clamp(k*d / travelled, 0, 1))).  With a = k*d >= travelled
-        // >= 0 the correctly rounded quotient is >= 1 (or +inf, or NaN for 0/0): the clamp gives 1
-        // (or keeps the NaN), smoothstep(1) = 1, and min(shade, 1 or NaN) leaves shade (<= 1) as it
-        // is.  Lanes in that case skip the division and the polynomial.
-        const float a = k * d;
-        float sh2 = shade;
-        // (travelled is a sum of earlier steps, each at least SMALL_DISTANCE, or the lane would have
-        // stopped: it is never negative in a running lane)
-        if (!(a >= travelled) && active) {
-            diag_event(4);
-            const float x = rs_clamp(RM_FAST ? a * __builtin_amdgcn_rcpf(travelled) : a / travelled, 0.0f, 1.0f);
-            const float ss = 3.0f * (x * x) - 2.0f * (x * (x * x));
-            sh2 = rs_min(shade, ss);
-        }
-        shade = sh2;
-        // a lane that has finished keeps stepping with values nobody reads: only `shade` leaves the loop
-        travelled += d;
-        pos = pos + dir * d;
-        act &= ~(lanes_lt(d, SMALL_DISTANCE) | lanes_gt(travelled, light_dist));
-        if (act == 0) break;
-    }
-    return rs_clamp(shade, 0.0f, 1.0f);
-}
+}  // namespace relaxed
 RM_FAST_END
-
-// `wanted` = false in a lane whose caller has no use for the value (it returns 1 there): such lanes
-// do not keep the wave's loop running, and a wave without a wanted lane skips it.
-template <class SC>
-RM_DEV float smooth_shadow_march(const SC &sc, V3 pos, V3 dir, int ignore, float light_dist, float k, bool wanted = true) {
-    const LaneMask want = __builtin_amdgcn_ballot_w64(wanted);
-    if (want == 0) return 1.0f;
-    if constexpr (SC::kGrid) return shadow_with(sc, pos, dir, LaneIgnore{ignore}, light_dist, k, want);
-    const int u = __builtin_amdgcn_readfirstlane(ignore);
-    if (wave_all(ignore == u)) return shadow_with(sc, pos, dir, UniformIgnore{u}, light_dist, k, want);
-    return shadow_with(sc, pos, dir, LaneIgnore{ignore}, light_dist, k, want);
-}
+#else
+namespace relaxed = ::rm;  // one arithmetic in the strict tier
+#endif
 
 // objects.rs:135-141 for a per-lane object.  The evaluations sit inside one dispatch on the type,
 // so a wave runs them only for the types its lanes hold.  `tetra` (the same in every lane) selects
@@ -1291,7 +858,8 @@ RM_DEV ShadeResult shade_local(const SC &sc, SceneRef sv_of_kernel, int idx, V3 
     // away from the light) the product is that zero for any shade - a finite value in [0, 1] - and the
     // shadow ray is not cast
     const bool lit = !(diffuse + specular == 0.0f);
-    float shade = (RM_ABL & 1) ? 1.0f : smooth_shadow_march(sc, pos, to_light, idx, dist, SHADOW_K, lit);
+    // (the shade is a continuous function of the ray's arithmetic: the fast tier marches it relaxed)
+    float shade = (RM_ABL & 1) ? 1.0f : relaxed::smooth_shadow_march(sc, pos, to_light, idx, dist, SHADOW_K, lit);
 
     diag_lap(DG_SHADOW);
     out.final_colour = ambient + oc * (shade * (diffuse + specular));
@@ -1320,7 +888,32 @@ RM_DEV V3 cast_sight_ray(const SC &sc, SceneRef sv, V3 pos, V3 dir, float first 
         bool capped;
         diag_lap(DG_REFLECT);
         diag_event(5);
-        int idx = march(sc, pos, dir, -1, sv.march_cap, steps, capped, first, first_sph);
+        int idx;
+#if RM_FAST && RM_FAST_PRIMARY
+        // Fast tier: the ray from the camera is first marched with the relaxed arithmetic.  Where it ends
+        // on a matt axis plane - whose normal is the axis whatever the last bits of the hit position
+        // are - everything that follows is a continuous function of that position, and the relaxed
+        // result stands.  Any other hit (a sphere, a box, a generic plane: normals that amplify the
+        // position's last bits; anything that reflects: the chain goes on from there) is marched
+        // again with the strict operations, for those lanes alone.  Mirror rays are always strict.
+        if (depth == 0 && depth0 == 0) {
+            const V3 start = pos;
+            idx = relaxed::march(sc, pos, dir, -1, sv.march_cap, steps, capped, first, first_sph);
+            bool again = false;
+            if (idx >= 0) {
+                const int type = sv.shade[idx].type;
+                again = !(type == T_XPLANE || type == T_YPLANE || type == T_ZPLANE) || sv.shade[idx].reflectivity > 1e-3f;
+            }
+            if (wave_any(again)) {
+                if (again) {
+                    V3 p = start;
+                    idx = march(sc, p, dir, -1, sv.march_cap, steps, capped, first, first_sph);
+                    pos = p;
+                }
+            }
+        } else
+#endif
+            idx = march(sc, pos, dir, -1, sv.march_cap, steps, capped, first, first_sph);
         first = __builtin_nanf("");  // known for the ray from the camera only
         if (capped) atomicAdd(&sv.stats[1], 1ULL);
         if (idx < 0) {
