@@ -70,18 +70,44 @@ def load_counters(width, height):
 
 
 def stress_roofline(width, height, kernel_ms):
-    """The stress frame against the FP32 vector peak.  No CPU oracle can count the algorithmic flops of
-    33 M pixels through 256 primitives, so the numerator is what the kernel executed: vector
-    lane-operations per launch from the committed rocprofv3 PMC pass (SQ_THREAD_CYCLES_VALU), each
-    counted as one flop, divided by the kernel time measured live."""
+    """The stress frame against the FP32 vector peak.  The numerator of `achieved` is what the kernel
+    executed: vector lane-operations per launch from the committed rocprofv3 PMC pass
+    (SQ_THREAD_CYCLES_VALU), each counted as one flop, divided by the kernel time measured live.  The
+    algorithmic flops - every object evaluated at every step, as the reference's loop does - are counted
+    by the oracle on a sample of rows and reported beside it (`algorithmic`): the spatial index
+    legitimately avoids nearly all of them, so they say nothing about how busy the vector units are."""
     try:
-        with open(os.path.join(ROOT, "profiles", "round2_stress_pmc.json")) as f:
-            pmc = json.load(f)
+        pmc = None
+        for name in ("round3_stress_pmc.json", "round2_stress_pmc.json"):
+            if os.path.exists(os.path.join(ROOT, "profiles", name)):
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    pmc = json.load(f)
+                break
+        if pmc is None:
+            return None
     except (OSError, ValueError):
         return None
     if (width, height) != (pmc.get("width"), pmc.get("height")) or not kernel_ms:
         return None
     achieved = pmc["valu_lane_ops_per_launch"] / (kernel_ms * 1e-3) / 1e12
+    algorithmic = None
+    try:
+        from raymarching_amd.flops import frame_flops
+
+        with open(os.path.join(ROOT, "tests", "golden", "counters.json")) as f:
+            c = json.load(f)[f"stress_rows_{width}x{height}"]
+        per_ray = frame_flops(c, smooth_union=True) / c["pixels"]
+        algorithmic = {
+            "flops_per_primary_ray": per_ray,
+            "flops_per_launch": per_ray * width * height,
+            "tflops_at_this_frame_time": per_ray * width * height / (kernel_ms * 1e-3) / 1e12,
+            "sample": f"the CPU oracle's counting build on rows {c['rows']} of the frame ({c['pixels']} pixels)",
+            "note": "the flops of the reference's algorithm, which evaluates every object at every step (ray.rs:19-40: 256 distances and a "
+                    "smooth-minimum fold per step); the kernel's spatial index proves most of them irrelevant and never computes them, "
+                    "so this rate exceeds the machine's peak and measures the index, not the vector units",
+        }
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        pass
     return {
         "bound": "valu",
         "achieved": achieved,
@@ -96,6 +122,7 @@ def stress_roofline(width, height, kernel_ms):
         "executed_lane_ops_per_launch": pmc["valu_lane_ops_per_launch"],
         "valu_instructions_per_launch": pmc.get("valu_instructions_per_launch"),
         "active_lanes_per_valu_instruction": pmc.get("active_lanes_per_valu_instruction"),
+        "algorithmic": algorithmic,
         "note": "executed vector lane-operations (SQ_THREAD_CYCLES_VALU), one flop each, not algorithmic flops: the oracle cannot count this "
                 "frame; the kernel is bound by the latency of its list walks (one VALU instruction per ~4 cycles per SIMD), not by issue",
     }

@@ -108,7 +108,9 @@ struct Counters {
     uint64_t max_depth = 0;        // deepest reflection recursion seen
     uint64_t max_march_steps = 0;  // longest single march seen
     uint64_t pixels = 0;
-    static constexpr int N = 25;
+    uint64_t march_box_sdf = 0;   // EXTENSION: box distance evaluations (sums, like the other sdf counts)
+    uint64_t shadow_box_sdf = 0;
+    static constexpr int N = 27;
     void add(const Counters &o) {
         const uint64_t *s = reinterpret_cast<const uint64_t *>(&o);
         uint64_t *d = reinterpret_cast<uint64_t *>(this);
@@ -622,10 +624,12 @@ static inline void count_sdf(int type, bool shadow) {
     if (shadow) {
         if (type == T_SPHERE) tl_counters.shadow_sphere_sdf++;
         else if (type == T_PLANE) tl_counters.shadow_gplane_sdf++;
+        else if (type == T_BOX) tl_counters.shadow_box_sdf++;
         else tl_counters.shadow_plane_sdf++;
     } else {
         if (type == T_SPHERE) tl_counters.march_sphere_sdf++;
         else if (type == T_PLANE) tl_counters.march_gplane_sdf++;
+        else if (type == T_BOX) tl_counters.march_box_sdf++;
         else tl_counters.march_plane_sdf++;
     }
 #else

@@ -89,9 +89,12 @@ struct MinWaves {
     static constexpr int value = 1;
 #endif
 };
+#ifndef RM_LARGE_MINWAVES
+#define RM_LARGE_MINWAVES 7
+#endif
 template <>
 struct MinWaves<GroupedLarge> {
-    static constexpr int value = 7;
+    static constexpr int value = RM_LARGE_MINWAVES;
 };
 // PLANS = false compiles the kernel without the plan and cost-table code (the 8-wave build, whose
 // launches are never planned, has no registers to spare for it).
@@ -248,6 +251,10 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, const G &g) {
 template <class G>
 struct MinWavesFrame {
     static constexpr int value = MinWaves<G>::value > 7 ? MinWaves<G>::value : 7;
+};
+template <>
+struct MinWavesFrame<GroupedLarge> {
+    static constexpr int value = MinWaves<GroupedLarge>::value;
 };
 template <class G>
 struct MinWavesDense {

@@ -15,6 +15,12 @@ renders it.
 SPHERE_SDF = 10  # 3 sub, 3 mul, 2 add, sqrt, sub
 AXIS_PLANE_SDF = 2  # sub, mul
 PLANE_SDF = 6  # 3 mul, 2 add, sub
+# extensions of the reference's object set (the stress scene): the box of objects.rs:370-380 - 3 sub,
+# 3 abs, 3 sub, 3 max, length (3 mul, 2 add, sqrt), max, max, min, add - and, with a smooth union, the
+# fold of one distance into the running value where the two are at least k apart (difference, magnitude,
+# compare besides the minimum that is counted anyway; the eight operations of an actual blend are not counted)
+BOX_SDF = 22
+SMOOTH_FOLD_EXTRA = 3
 # Ray::march per iteration besides the sdfs: one compare per object, hit test,
 # loop test, travelled add, position update (3 mul + 3 add)      (ray.rs:19-39)
 MARCH_STEP = 9
@@ -32,11 +38,14 @@ REFLECTION = 47  # engine.rs:231-241 besides the recursive ray
 TONEMAP = 42  # exposure, ACES, sqrt, to_pixel_range for 3 channels
 
 
-def frame_flops(c):
+def frame_flops(c, smooth_union=False):
     """c: dict of oracle counters for one frame.  Returns the flop total."""
-    march_sdf = c["march_sphere_sdf"] + c["march_plane_sdf"] + c["march_gplane_sdf"]
-    shadow_sdf = c["shadow_sphere_sdf"] + c["shadow_plane_sdf"] + c["shadow_gplane_sdf"]
-    total = 0
+    march_box, shadow_box = c.get("march_box_sdf", 0), c.get("shadow_box_sdf", 0)
+    march_sdf = c["march_sphere_sdf"] + c["march_plane_sdf"] + c["march_gplane_sdf"] + march_box
+    shadow_sdf = c["shadow_sphere_sdf"] + c["shadow_plane_sdf"] + c["shadow_gplane_sdf"] + shadow_box
+    total = BOX_SDF * (march_box + shadow_box)
+    if smooth_union:
+        total += SMOOTH_FOLD_EXTRA * (march_sdf + shadow_sdf)
     total += SPHERE_SDF * (c["march_sphere_sdf"] + c["shadow_sphere_sdf"])
     total += AXIS_PLANE_SDF * (c["march_plane_sdf"] + c["shadow_plane_sdf"])
     total += PLANE_SDF * (c["march_gplane_sdf"] + c["shadow_gplane_sdf"])

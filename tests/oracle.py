@@ -18,6 +18,7 @@ COUNTER_NAMES = (
     "normals_sphere", "normals_plane", "normals_gplane", "shade_calls", "lightmap_samples",
     "lightmap_resamples", "lightmap_oob", "texture_samples", "powf_calls", "atan2_calls",
     "reflection_rays", "sky_hits", "max_depth", "max_march_steps", "pixels",
+    "march_box_sdf", "shadow_box_sdf",
 )
 
 _F = POINTER(c_float)
