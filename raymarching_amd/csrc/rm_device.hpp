@@ -243,12 +243,30 @@ RM_DEV float sdf_eval(int type, const Geom &g, V3 p) {
 
 // Polynomial smooth minimum for "smooth unions" (an extension: the reference's union is the hard
 // minimum of ray.rs:23-33).
-RM_DEV float smooth_min(float a, float b, float k) {
+// The blend width travels with its reciprocal: h = max(k - gap, 0) / k is then the quotient with
+// shared work on the divisor (div_rn_in_range: four operations, the same correctly rounded value as
+// the IEEE division's ten).  That form needs every intermediate to stay normal: the dividend lies
+// in [0, k] and, where it is not zero, is at least one unit in the last place of k, so widths between
+// 2^-60 and 2^60 qualify; any other width keeps the plain division (kr = 0).
+struct BlendK {
+    float k, kr;
+    RM_DEV operator float() const { return k; }
+};
+RM_DEV float recip_rn_in_range(float b);
+RM_DEV float div_rn_in_range(float a, float b, float y);
+RM_DEV BlendK blend_k(float k) {
+    BlendK b;
+    b.k = k;
+    b.kr = (k >= 0x1p-60f && k <= 0x1p60f) ? recip_rn_in_range(k) : 0.0f;
+    return b;
+}
+RM_DEV float smooth_min(float a, float b, BlendK k) {
     // |a - b| >= k makes h = 0 / k = 0 and the result min(a, b) - 0: no division needed then
     const float gap = fabsf(a - b);
-    if (gap >= k) return rs_min(a, b);
-    float h = rs_max(k - gap, 0.0f) / k;
-    return rs_min(a, b) - h * h * k * (1.0f / 4.0f);
+    if (gap >= k.k) return rs_min(a, b);
+    const float num = rs_max(k.k - gap, 0.0f);
+    float h = k.kr != 0.0f ? div_rn_in_range(num, k.k, k.kr) : num / k.k;
+    return rs_min(a, b) - h * h * k.k * (1.0f / 4.0f);
 }
 
 // Correctly rounded square root.  v_sqrt_f32 is within one ulp; its residual x - s*s (exact in one
@@ -522,6 +540,9 @@ typedef Float16 __attribute__((aligned(4))) Float16u;
 typedef Int4 __attribute__((aligned(4))) Int4u;
 typedef const __attribute__((address_space(4))) Float16u *ConstFloat16s;
 typedef const __attribute__((address_space(4))) Int4u *ConstInt4us;
+typedef int Int8 __attribute__((ext_vector_type(8)));
+typedef Int8 __attribute__((aligned(4))) Int8u;
+typedef const __attribute__((address_space(4))) Int8u *ConstInt8us;
 
 // The march family: strict here, and once more with relaxed arithmetic for the fast tier.
 constexpr bool kRelaxedMarch = false;
@@ -532,7 +553,8 @@ namespace relaxed {
 typedef VC V3;  // (inside this namespace the march family computes with the vector type whose operators may fuse)
 RM_DEV VC v3(float x, float y, float z) { return vc(x, y, z); }
 RM_DEV float sqrt_rn(float x) { return __builtin_amdgcn_sqrtf(x); }
-RM_DEV float smooth_min(float a, float b, float k) {
+RM_DEV float smooth_min(float a, float b, BlendK bk) {
+    const float k = bk.k;
     const float gap = fabsf(a - b);
     if (gap >= k) return rs_min(a, b);
     const float h = rs_max(k - gap, 0.0f) * __builtin_amdgcn_rcpf(k);
@@ -830,7 +852,7 @@ struct ShadeResult {
 
 // engine.rs:147-194: everything of shade_object before the reflection branch.
 template <class SC>
-RM_DEV ShadeResult shade_local(const SC &sc, SceneRef sv_of_kernel, int idx, V3 pos, V3 dir) {
+RM_DEV ShadeResult shade_local(const SC &sc, SceneRef sv_of_kernel, int idx, V3 &pos, V3 &dir) {  // (pos and dir come back as they went in: by reference so that a caller need not keep copies across the shadow ray)
     SceneRef sv = scene_here(sv_of_kernel);
     const ShadeRec sr = sv.shade[idx];
     const Geom g = sv.geom[idx];
@@ -859,13 +881,54 @@ RM_DEV ShadeResult shade_local(const SC &sc, SceneRef sv_of_kernel, int idx, V3 
     // shadow ray is not cast
     const bool lit = !(diffuse + specular == 0.0f);
     // (the shade is a continuous function of the ray's arithmetic: the fast tier marches it relaxed)
+    float ds = diffuse + specular;
+    float reflectivity = sr.reflectivity;
+#if !defined(RM_NO_STASH)
+    // Large scenes: the march loops need every register the kernel has at seven waves per SIMD, and
+    // what this function holds across the shadow ray would otherwise be spilled to private memory -
+    // HBM traffic of about 100 bytes per pixel.  These values wait in LDS instead (a wave is a
+    // workgroup of its own and nothing else uses LDS: 4 KiB per wave, 112 KiB per compute unit).
+    constexpr bool kStash = SC::kGrid;
+    __shared__ float stash[kStash ? 16 : 1][64];
+    const int stash_lane = threadIdx.x & 63;
+    if constexpr (kStash) {
+        stash[0][stash_lane] = oc.x;
+        stash[1][stash_lane] = oc.y;
+        stash[2][stash_lane] = oc.z;
+        stash[3][stash_lane] = ambient.x;
+        stash[4][stash_lane] = ambient.y;
+        stash[5][stash_lane] = ambient.z;
+        stash[6][stash_lane] = n.x;
+        stash[7][stash_lane] = n.y;
+        stash[8][stash_lane] = n.z;
+        stash[9][stash_lane] = ds;
+        stash[10][stash_lane] = dir.x;
+        stash[11][stash_lane] = dir.y;
+        stash[12][stash_lane] = dir.z;
+        stash[13][stash_lane] = pos.x;
+        stash[14][stash_lane] = pos.y;
+        stash[15][stash_lane] = pos.z;
+        asm volatile("" ::: "memory");
+    }
+#endif
     float shade = (RM_ABL & 1) ? 1.0f : relaxed::smooth_shadow_march(sc, pos, to_light, idx, dist, SHADOW_K, lit);
+#if !defined(RM_NO_STASH)
+    if constexpr (kStash) {
+        asm volatile("" ::: "memory");
+        oc = vc(stash[0][stash_lane], stash[1][stash_lane], stash[2][stash_lane]);
+        ambient = vc(stash[3][stash_lane], stash[4][stash_lane], stash[5][stash_lane]);
+        n = v3(stash[6][stash_lane], stash[7][stash_lane], stash[8][stash_lane]);
+        ds = stash[9][stash_lane];
+        dir = v3(stash[10][stash_lane], stash[11][stash_lane], stash[12][stash_lane]);
+        pos = v3(stash[13][stash_lane], stash[14][stash_lane], stash[15][stash_lane]);
+    }
+#endif
 
     diag_lap(DG_SHADOW);
-    out.final_colour = ambient + oc * (shade * (diffuse + specular));
+    out.final_colour = ambient + oc * (shade * ds);
     out.object_colour = oc;
     out.n = n;
-    out.reflectivity = sr.reflectivity;
+    out.reflectivity = reflectivity;
     return out;
 }
 

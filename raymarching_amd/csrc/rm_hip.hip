@@ -1208,9 +1208,10 @@ static int engine_upload(rm_engine *e) {
             const double ex[3] = {(double)bhi[0] - blo[0], (double)bhi[1] - blo[1], (double)bhi[2] - blo[2]};
             const double longest = std::max(ex[0], std::max(ex[1], ex[2]));
             if (finite && longest > 0.0) {
-                // Mean spacing of the primitives; cells a quarter of it, base reach 0.85 of it plus the
+                // Mean spacing of the primitives; cells a quarter of it, base reach equal to it plus the
                 // blend width (the fastest of a sweep over both on the 250-primitive stress scenes: longer
-                // lists cost more than the full walks that shorter ones cause).  A cell with fewer than
+                // lists cost more than the full walks that shorter ones cause; the reach was 0.85 of the
+                // spacing until a wave could pass over a listed primitive with one compare).  A cell with fewer than
                 // kGridMinList primitives within the base reach takes the reach that admits that many, so
                 // that open space far from everything still gets the few nearest primitives and a large
                 // reach instead of a full walk; kGridMaxList caps a list by lowering the cell's reach.
@@ -1227,7 +1228,7 @@ static int engine_upload(rm_engine *e) {
                     const char *v = getenv(name);
                     return std::max(1, std::min({v ? atoi(v) : dflt, n_bounded, 65535}));
                 };
-                const double reach_mul = env_mul("RM_GRID_REACH", 0.85);
+                const double reach_mul = env_mul("RM_GRID_REACH", 1.0);
                 const double cell_mul = env_mul("RM_GRID_CELL", 0.25);
                 const int min_list = env_count("RM_GRID_MINLIST", kGridMinList);
                 const int max_list = std::max(min_list, env_count("RM_GRID_MAXLIST", kGridMaxList));
@@ -1264,7 +1265,9 @@ static int engine_upload(rm_engine *e) {
                 const float origin[3] = {gv.ox, gv.oy, gv.oz};
                 // phase 1, host threads over slabs of cells: every cell's reach and member list per level
                 std::vector<std::vector<uint16_t>> members[kGridLevels];
+                std::vector<std::vector<float>> member_lb[kGridLevels];  // each member's distance bound over the cell
                 for (auto &m : members) m.resize(gv.cells);
+                for (auto &m : member_lb) m.resize(gv.cells);
                 auto slab = [&](int z0, int z1) {
                     std::vector<float> lb(n_bounded), sorted(n_bounded);
                     for (int cz = z0; cz < z1; cz++)
@@ -1308,7 +1311,10 @@ static int engine_upload(rm_engine *e) {
                                     if (n_bounded > plans[L].max_list && sorted[plans[L].max_list] < r) r = sorted[plans[L].max_list];
                                     lv[L].cell_reach[c] = r;
                                     for (int i = 0; i < n_bounded; i++)
-                                        if (lb[i] < r) members[L][c].push_back((uint16_t)i);
+                                        if (lb[i] < r) {
+                                            members[L][c].push_back((uint16_t)i);
+                                            member_lb[L][c].push_back(lb[i]);
+                                        }
                                 }
                             }
                 };
@@ -1332,7 +1338,12 @@ static int engine_upload(rm_engine *e) {
                     int longest_list = 0;
                     for (int c = 0; c < gv.cells; c++) {
                         std::vector<int> sph, box;
-                        for (uint16_t i : members[L][c]) (i < gi_sph.size() ? sph : box).push_back(i);
+                        std::vector<float> sph_lb, box_lb;
+                        for (size_t m = 0; m < members[L][c].size(); m++) {
+                            const uint16_t i = members[L][c][m];
+                            (i < gi_sph.size() ? sph : box).push_back(i);
+                            (i < gi_sph.size() ? sph_lb : box_lb).push_back(member_lb[L][c][m]);
+                        }
                         const size_t s_at = pool.size();
                         for (size_t g0 = 0; g0 < sph.size(); g0 += 4) {
                             int group[kGridSphereGroup];
@@ -1340,16 +1351,17 @@ static int engine_upload(rm_engine *e) {
                                 const bool there = g0 + u < sph.size();
                                 for (int w = 0; w < 4; w++) group[4 * u + w] = there ? word(g_sph[4 * sph[g0 + u] + w]) : 0;
                                 group[16 + u] = there ? gi_sph[sph[g0 + u]] : -1;
+                                group[20 + u] = word(there ? sph_lb[g0 + u] : INFINITY);
                             }
                             pool.insert(pool.end(), group, group + kGridSphereGroup);
                         }
                         const size_t b_at = pool.size();
-                        for (int i : box) {
-                            const int b = i - (int)gi_sph.size();
+                        for (size_t m = 0; m < box.size(); m++) {
+                            const int b = box[m] - (int)gi_sph.size();
                             int rec[8];
                             for (int w = 0; w < 6; w++) rec[w] = word(g_box[8 * b + w]);
                             rec[6] = gi_box[b];
-                            rec[7] = 0;
+                            rec[7] = word(box_lb[m]);
                             pool.insert(pool.end(), rec, rec + 8);
                         }
                         int *rec = &pool[4 * ((size_t)L * gv.cells + c)];
@@ -1365,7 +1377,7 @@ static int engine_upload(rm_engine *e) {
                         fprintf(stderr, "rm: spatial index level %d: %d x %d x %d cells of %.3f, base reach %.3f, apron %.3f, %zu entries (%.1f per cell, longest list %d) for %d primitives\n",
                                 L, gv.nx, gv.ny, gv.nz, cell, plans[L].base, apron, entries, (double)entries / gv.cells, longest_list, n_bounded);
                 }
-                pool.resize(pool.size() + 16, 0);  // a wave-uniform walk fetches whole groups and pairs
+                pool.resize(pool.size() + 24, 0);  // a wave-uniform walk fetches whole groups and pairs
                 if (pool.size() > (size_t)INT32_MAX) return fail(RM_ERR_INVALID, "the spatial index of this scene would not fit 32-bit offsets");
                 HIP_TRY(up_i(pool, &gv.pool));
                 gl.grid = gv;

@@ -87,13 +87,17 @@ typedef GroupedSmall<4, 4, 2> GroupedTierB;
 //   * the cell table of level L at dword 4 * cells * L, one record of four dwords per cell: where the
 //     cell's sphere block starts, where its box block starts (dword offsets into the pool),
 //     sphere count | box count << 16, and the cell's reach (float bits);
-//   * a sphere block: groups of four spheres, 20 dwords each: cx, cy, cz, r of the four, then their
-//     four object indices (the last group is filled up with zeros and -1);
-//   * a box block: eight dwords per box: cx, cy, cz, hx, hy, hz, object index, -.
+//   * a sphere block: groups of four spheres, 24 dwords each: cx, cy, cz, r of the four, then their
+//     four object indices (the last group is filled up with zeros and -1), then for each of the four a
+//     lower bound of its distance over the whole cell;
+//   * a box block: eight dwords per box: cx, cy, cz, hx, hy, hz, object index, the same lower bound.
+// The lower bounds let a wave whose lanes share a cell pass over an entry with one compare: where no
+// lane's running value (plus the blend width) reaches an entry's bound, the entry cannot change
+// any lane's fold.
 // Blocks start at multiples of four dwords; the pool ends with sixteen dwords of padding, since a
 // wave-uniform walk fetches a whole group of spheres or a pair of boxes at once.
 constexpr int kGridLevels = 2;
-constexpr int kGridSphereGroup = 20;  // dwords per group of four spheres
+constexpr int kGridSphereGroup = 24;  // dwords per group of four spheres
 struct GridView {
     int nx, ny, nz, cells;
     float ox, oy, oz;   // lower corner
