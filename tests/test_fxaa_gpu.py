@@ -44,11 +44,13 @@ def test_fxaa_bit_exact(scene, oracle_lightmaps):
     e.close()
 
 
-@pytest.mark.parametrize("size", [(403, 301), (64, 40), (131, 9), (9, 131)])
+@pytest.mark.parametrize("size", [(403, 301), (64, 40), (131, 9), (9, 131), (404, 301), (496, 50), (500, 37), (252, 64), (8, 40), (12, 131)])
 def test_fxaa_around_the_edge_threshold(scene, size):
     """Images that sweep through the point where the taps leave the pixel: brightness ramps across,
     the amplitude of a small noise ramps down the image, so scaled directions of every size near 1
-    occur at every brightness.  Odd sizes, and frames barely larger than the untouched border."""
+    occur at every brightness.  Odd sizes, and frames barely larger than the untouched border; widths
+    that are multiples of 4 take the kernel with four pixels per lane (one wave's 248 columns, two
+    waves' worth, a last wave with a few columns), the others the kernel with one."""
     import torch
 
     import oracle
