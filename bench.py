@@ -628,66 +628,71 @@ def main():
         if last_presenter is None or last_presenter == rank:
             checks[args.exchange] = bool(torch.equal(final[last_buf], local))
     if gathering and not args.no_extras:
-        calib = 16
-        # (a) this rank's share rendered alone and the collective alone: one frame at a time, nothing else on the GPU
-        group.set_exchange("all_gather")
-        group.set_timing(True)
-        for s in range(calib):
-            group.frame(final[s % n_buf].data_ptr(), args.fxaa)
-            group.wait()
-        share_ms, _ = group.render_time()
-        ag_ms, _ = group.exchange_time()
-        group.set_exchange("presenter")
-        group.set_timing(True)
-        for s in range(calib):
-            group.frame(final[s % n_buf].data_ptr(), args.fxaa)
-            group.wait()
-        pr_ms, _ = group.exchange_time()
-        group.set_timing(False)
-        kernel_alone_ms = share_ms
-        # (b) the whole frame on this rank alone, every rank at the same time: what one GPU does without the group
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(calib):
-            render_local()
-        torch.cuda.synchronize()
-        n1_ms = (time.perf_counter() - t0) / calib * 1e3
-        # (c) the other exchange, timed like the headline
-        other = "presenter" if args.exchange == "all_gather" else "all_gather"
-        group.set_exchange(other)
-        run(args.warmup, False)
-        other_elapsed = timed_region(args.steps)
-        other_last = (args.steps - 1) % n_buf
-        if other == "all_gather" or (group.next_presenter() - 1) % world == rank:
-            checks[other] = bool(torch.equal(final[other_last], local))
-        if world > 1:
-            t = torch.tensor([share_ms, ag_ms, pr_ms, n1_ms], dtype=torch.float64)
-            tmax, tmean = t.clone(), t.clone()
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dist.all_reduce(tmean, op=dist.ReduceOp.SUM)
-            tmean /= world
-            gathered_checks = [None] * world
-            dist.all_gather_object(gathered_checks, checks)
-            checks = {k: all(c[k] for c in gathered_checks if k in c) for k in ("all_gather", "presenter") if any(k in c for c in gathered_checks)}
-        else:
-            tmax = tmean = torch.tensor([share_ms, ag_ms, pr_ms, n1_ms], dtype=torch.float64)
-        ms_per_step = elapsed / args.steps * 1e3
-        other_ms = other_elapsed / args.steps * 1e3
-        extras = {
-            "render_share_ms": {"mean": float(tmean[0]), "max_over_ranks": float(tmax[0]),
-                                "note": "this rank's strips rendered alone (one frame at a time, events around the launch)"},
-            "exchange_ms": {"all_gather": {"mean": float(tmean[1]), "max_over_ranks": float(tmax[1])},
-                            "presenter_gather": {"mean": float(tmean[2]), "max_over_ranks": float(tmax[2])},
-                            "note": "the collective alone, one frame at a time (events around it on the frame's stream)"},
-            "n1_ms_per_frame": {"mean": float(tmean[3]), "max_over_ranks": float(tmax[3]),
-                                "note": "the whole frame on one rank's GPU without the group, every rank at the same time"},
-            "efficiency_vs_n1": float(tmean[3]) / (world * ms_per_step),
-            "other_exchange": {"exchange": other, "ms_per_step": other_ms, "value": W * H * (4 if args.ssaa else 1) / (other_ms * 1e-3) / 1e6,
-                               "unit": "Mrays/s", "efficiency_vs_n1": float(tmean[3]) / (world * other_ms), "steps": args.steps,
-                               "note": "the same frames through the other exchange, timed like the headline"},
-            "communicators": group.communicators(),
-        }
-        exchange_ms = extras["exchange_ms"]
+        # (none of this is `value`: a failure here - a build of RCCL without a gather, say - must not cost the line)
+        try:
+            calib = 16
+            # (a) this rank's share rendered alone and the collective alone: one frame at a time, nothing else on the GPU
+            group.set_exchange("all_gather")
+            group.set_timing(True)
+            for s in range(calib):
+                group.frame(final[s % n_buf].data_ptr(), args.fxaa)
+                group.wait()
+            share_ms, _ = group.render_time()
+            ag_ms, _ = group.exchange_time()
+            group.set_exchange("presenter")
+            group.set_timing(True)
+            for s in range(calib):
+                group.frame(final[s % n_buf].data_ptr(), args.fxaa)
+                group.wait()
+            pr_ms, _ = group.exchange_time()
+            group.set_timing(False)
+            kernel_alone_ms = share_ms
+            # (b) the whole frame on this rank alone, every rank at the same time: what one GPU does without the group
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(calib):
+                render_local()
+            torch.cuda.synchronize()
+            n1_ms = (time.perf_counter() - t0) / calib * 1e3
+            # (c) the other exchange, timed like the headline
+            other = "presenter" if args.exchange == "all_gather" else "all_gather"
+            group.set_exchange(other)
+            run(args.warmup, False)
+            other_elapsed = timed_region(args.steps)
+            other_last = (args.steps - 1) % n_buf
+            if other == "all_gather" or (group.next_presenter() - 1) % world == rank:
+                checks[other] = bool(torch.equal(final[other_last], local))
+            if world > 1:
+                t = torch.tensor([share_ms, ag_ms, pr_ms, n1_ms], dtype=torch.float64)
+                tmax, tmean = t.clone(), t.clone()
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(tmean, op=dist.ReduceOp.SUM)
+                tmean /= world
+                gathered_checks = [None] * world
+                dist.all_gather_object(gathered_checks, checks)
+                checks = {k: all(c[k] for c in gathered_checks if k in c) for k in ("all_gather", "presenter") if any(k in c for c in gathered_checks)}
+            else:
+                tmax = tmean = torch.tensor([share_ms, ag_ms, pr_ms, n1_ms], dtype=torch.float64)
+            ms_per_step = elapsed / args.steps * 1e3
+            other_ms = other_elapsed / args.steps * 1e3
+            extras = {
+                "render_share_ms": {"mean": float(tmean[0]), "max_over_ranks": float(tmax[0]),
+                                    "note": "this rank's strips rendered alone (one frame at a time, events around the launch)"},
+                "exchange_ms": {"all_gather": {"mean": float(tmean[1]), "max_over_ranks": float(tmax[1])},
+                                "presenter_gather": {"mean": float(tmean[2]), "max_over_ranks": float(tmax[2])},
+                                "note": "the collective alone, one frame at a time (events around it on the frame's stream)"},
+                "n1_ms_per_frame": {"mean": float(tmean[3]), "max_over_ranks": float(tmax[3]),
+                                    "note": "the whole frame on one rank's GPU without the group, every rank at the same time"},
+                "efficiency_vs_n1": float(tmean[3]) / (world * ms_per_step),
+                "other_exchange": {"exchange": other, "ms_per_step": other_ms, "value": W * H * (4 if args.ssaa else 1) / (other_ms * 1e-3) / 1e6,
+                                   "unit": "Mrays/s", "efficiency_vs_n1": float(tmean[3]) / (world * other_ms), "steps": args.steps,
+                                   "note": "the same frames through the other exchange, timed like the headline"},
+                "communicators": group.communicators(),
+            }
+            exchange_ms = extras["exchange_ms"]
+        except Exception as exc:  # noqa: BLE001
+            extras = {"extras_failed": f"{type(exc).__name__}: {exc}"[:300]}
+            print(f"[bench] rank {rank}: secondary measurements failed: {extras['extras_failed']}", file=sys.stderr)
     elif not gathering and not args.no_extras and args.workload == "render" and not args.ssaa and not args.refraction:
         # the shader clock under this load: the probe wave runs beside frames that are enqueued first
         run(60 if W * H <= 1920 * 1080 else 30, False)
@@ -758,7 +763,7 @@ def main():
         if gathering:
             # with frames in flight the events around one launch span other launches too: the roofline is
             # that of this rank's share rendered alone, or nothing
-            roof_kernel_ms = extras["render_share_ms"]["mean"] if extras else None
+            roof_kernel_ms = extras["render_share_ms"]["mean"] if "render_share_ms" in extras else None
         if counters is not None and roof_kernel_ms:
             band_share = (r1 - r0) / H  # flops are counted for the whole frame; a band is its share by rows
             flops = frame_flops(counters)

@@ -939,11 +939,22 @@ RM_DEV ShadeResult shade_local(const SC &sc, SceneRef sv_of_kernel, int idx, V3 
 template <class SC>
 RM_DEV V3 cast_sight_ray(const SC &sc, SceneRef sv, V3 pos, V3 dir, float first = __builtin_nanf(""),
                          float first_sph = __builtin_nanf(""), int depth0 = 0) {
-    // (The frames live in private memory, 28 bytes each: their writes are what the kernel's HBM write
-    // traffic has beyond the pixels.  Keeping the first frame - the only one most reflecting pixels ever
-    // open - in registers was measured: 80 instead of 72 vector registers, 6 instead of 7 waves per SIMD,
-    // and the frame 2 % slower; the traffic costs no time at 0.2 TB/s.)
+    // (The frames, 28 bytes each, live in private memory from the third on.  Keeping the first frame in
+    // registers was measured: 80 instead of 72 vector registers, 6 instead of 7 waves per SIMD, and the
+    // frame 2 % slower.)
     float stk[MAX_DEPTH][7];
+    // The first two frames of the stack - all that most reflecting pixels ever open - wait in LDS
+    // (a wave is a workgroup of its own: 3.5 KiB for two frames of 64 lanes, 112 KiB per compute unit at
+    // eight waves per SIMD): the kernel's HBM traffic beyond the pixels it writes was these frames'
+    // (3840x2160: 100 -> 42 MB per launch for 33 MB of pixels).  Large scenes keep their LDS for the
+    // values held across the shadow ray.
+#if defined(RM_NO_LDS_STACK)
+    constexpr int kLdsFrames = 0;
+#else
+    constexpr int kLdsFrames = SC::kGrid ? 0 : 2;
+#endif
+    __shared__ float lds_stk[kLdsFrames > 0 ? kLdsFrames : 1][7][64];
+    const int stk_lane = threadIdx.x & 63;
     int depth = 0;
     VC colour;
     for (;;) {
@@ -997,13 +1008,14 @@ RM_DEV V3 cast_sight_ray(const SC &sc, SceneRef sv, V3 pos, V3 dir, float first 
             float fresnel = powi5(rs_clamp(1.0f - dot(r.n, -dir), 0.0f, 1.0f));
             V3 rv = reflect(dir, r.n);
             float kk = rs_clamp(fresnel + r.reflectivity, 0.0f, 1.0f);
-            stk[depth][0] = r.final_colour.x;
-            stk[depth][1] = r.final_colour.y;
-            stk[depth][2] = r.final_colour.z;
-            stk[depth][3] = r.object_colour.x;
-            stk[depth][4] = r.object_colour.y;
-            stk[depth][5] = r.object_colour.z;
-            stk[depth][6] = kk;
+            const float frame[7] = {r.final_colour.x, r.final_colour.y, r.final_colour.z, r.object_colour.x, r.object_colour.y, r.object_colour.z, kk};
+            if (kLdsFrames > 0 && depth < kLdsFrames) {
+#pragma unroll
+                for (int w = 0; w < 7; w++) lds_stk[depth][w][stk_lane] = frame[w];
+            } else {
+#pragma unroll
+                for (int w = 0; w < 7; w++) stk[depth][w] = frame[w];
+            }
             depth++;
             pos = pos + ((rv * 3.0f) * SMALL_DISTANCE);  // engine.rs:237
             dir = rv;
@@ -1014,9 +1026,17 @@ RM_DEV V3 cast_sight_ray(const SC &sc, SceneRef sv, V3 pos, V3 dir, float first 
     }
     while (depth > 0) {
         depth--;
-        VC f = vc(stk[depth][0], stk[depth][1], stk[depth][2]);
-        VC oc = vc(stk[depth][3], stk[depth][4], stk[depth][5]);
-        colour = f + emul(colour, oc) * stk[depth][6];  // engine.rs:239-240
+        float frame[7];
+        if (kLdsFrames > 0 && depth < kLdsFrames) {
+#pragma unroll
+            for (int w = 0; w < 7; w++) frame[w] = lds_stk[depth][w][stk_lane];
+        } else {
+#pragma unroll
+            for (int w = 0; w < 7; w++) frame[w] = stk[depth][w];
+        }
+        VC f = vc(frame[0], frame[1], frame[2]);
+        VC oc = vc(frame[3], frame[4], frame[5]);
+        colour = f + emul(colour, oc) * frame[6];  // engine.rs:239-240
     }
     return colour;
 }

@@ -1,7 +1,7 @@
 """Parity at the sizes bench.py measures: the 3840x2160 default frame, the 1920x1080 frame with FXAA,
 rows of the 7680x4320 stress frame, and the lightmaps at a MAP_SIZE whose bounce runs over several
 slabs of form factors.  The oracle renders these in seconds (whole 4K frame: a few seconds of CPU;
-the stress scene: eight rows)."""
+the stress scene: twelve rows)."""
 import hashlib
 import os
 
@@ -72,12 +72,12 @@ def test_1080p_render_then_fxaa_chain(scene, oracle_lightmaps):
 
 
 def test_stress_frame_rows_at_7680x4320():
-    """Config "256 mixed primitives with smooth unions, 7680x4320, march cap 1024": eight rows spread
+    """Config "256 mixed primitives with smooth unions, 7680x4320, march cap 1024": twelve rows spread
     over the frame against the oracle's full fold over all primitives, no march cut by the cap, and
-    the whole frame bit-stable from run to run.  Four of the rows are rendered from the lightmaps of
+    the whole frame bit-stable from run to run.  Six of the rows are rendered from the lightmaps of
     the library's own precompute on this scene (11072 patches: hours for the oracle, whose parity on
     the precompute is pinned on the smaller scenes; here the oracle renders from the same values),
-    four from a fixed smooth pattern, which keeps more of the frame below the tone map's white."""
+    six from a fixed smooth pattern, which keeps more of the frame below the tone map's white."""
     import torch
 
     from raymarching_amd import Engine
@@ -111,19 +111,19 @@ def test_stress_frame_rows_at_7680x4320():
             mx, exact = frame_stats(host[y:y + 1], ref)
             worst, off = max(worst, mx), off + round((1 - exact) * w)
         print(f"7680x4320 stress rows {rows}, {what}: max|d| = {worst}, {off} of {len(rows) * w} pixels differ")
-        assert worst <= 1 and off <= 2
+        assert worst <= 1 and off <= 3
 
     eng.compute_lightmaps(4)  # what the benchmark does before its frame loop
     for i in lit:
         values = eng.get_lightmap(i)
         assert np.isfinite(values).all()
         ora.set_lightmap(i, values)
-    rows_against_oracle(rendered_twice(), [611, 2160, 3333, 4319], "lightmaps of the precompute")
+    rows_against_oracle(rendered_twice(), [611, 1207, 2160, 2950, 3333, 4319], "lightmaps of the precompute")
     lm = stress_lightmap_pattern()
     for i in lit:
         eng.set_lightmap(i, lm)
         ora.set_lightmap(i, lm)
-    rows_against_oracle(rendered_twice(), [5, 1500, 2701, 3900], "pattern lightmaps")
+    rows_against_oracle(rendered_twice(), [5, 800, 1500, 2701, 3900, 4100], "pattern lightmaps")
     eng.close()
     ora.close()
 
