@@ -381,7 +381,10 @@ int rm_group_compute_lightmaps(rm_group *group, int bounces);
 
 /* Engine::render (engine.rs:38-127) for the group, one call per rank and frame: the input block is
  * applied (every rank passes the same values and so keeps the same camera), this rank's strips are
- * rendered, all-gathered and put in row order, and with fxaa != 0 the gathered frame is filtered
+ * rendered (in the group's i-th frame rank r takes the strips (r + i) mod world, (r + i) mod world +
+ * world, ...: the assignment rotates, so that the few strips with a view's slowest tiles are not the
+ * same rank's in every frame; RM_GROUP_ROTATE=0 in every rank's environment pins rank r to strips r,
+ * r + world, ...), all-gathered and put in row order, and with fxaa != 0 the gathered frame is filtered
  * (fxaa.txt, as rm_engine_fxaa_device) - the whole frame, B,G,R,0 rows of width*4 bytes, lands in
  * `d_bgra_frame` (device memory) on every rank.  Asynchronous: the call only enqueues; frame f and
  * frame f + frames_in_flight share a stream and buffers, all others overlap.  Collective: every rank

@@ -28,12 +28,12 @@
 // Strips as an all-gather of 4-byte pixels leaves them -> rows in frame order (the unpacked
 // counterpart of unpack_bgr_strips_kernel, for frame widths that are not a multiple of 4).
 __global__ __launch_bounds__(256) void reorder_strips_kernel(const unsigned *__restrict__ src, unsigned *__restrict__ dst, int W, int H,
-                                                             int world, int per) {
+                                                             int world, int per, int shift) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W) return;
     const int s = y / RM_STRIP_ROWS;
-    const size_t srow = (size_t)((s % world) * per + s / world) * RM_STRIP_ROWS + (y % RM_STRIP_ROWS);
+    const size_t srow = (size_t)(((s % world - shift + world) % world) * per + s / world) * RM_STRIP_ROWS + (y % RM_STRIP_ROWS);
     dst[(size_t)y * W + x] = src[srow * W + x];
 }
 
@@ -139,6 +139,8 @@ struct rm_group {
     void *custom_gather_user = nullptr;
     int exchange = RM_EXCHANGE_ALL_GATHER;
     unsigned long long frames = 0;  // frames issued in the current exchange mode: frame f's presenter is rank f mod world
+    unsigned long long issued = 0;  // frames issued since the group was made: which strips a rank renders rotates with it
+    bool rotate = true;
     int strips_per_rank = 0;
     size_t band_pixels = 0;  // pixels of one rank's part (padded to whole strips)
     bool packed = false;     // 3 bytes per pixel on the wire
@@ -210,7 +212,7 @@ static void group_free(rm_group *g) {
             auto &att = e->attached_streams;
             att.erase(std::remove(att.begin(), att.end(), s.stream), att.end());
             // the launch plan the stream's frames had goes with it (a later stream may get the same handle)
-            for (unsigned i = 0; i < 8; i++)
+            for (unsigned i = 0; i < rm_engine::kPlans; i++)
                 if (e->plan_taken[i] && e->plan_stream[i] == s.stream) {
                     e->plan_taken[i] = false;
                     e->plan_stream[i] = nullptr;
@@ -277,6 +279,7 @@ static rm_group *group_build(rm_engine *e, int rank, int world, int frames_in_fl
     g->in_flight = frames_in_flight;
     const int strips = (e->H + RM_STRIP_ROWS - 1) / RM_STRIP_ROWS;
     g->strips_per_rank = (strips + world - 1) / world;
+    if (const char *v = getenv("RM_GROUP_ROTATE")) g->rotate = atoi(v) != 0;  // (the same on every rank; 0 = rank r always renders strips r, r + world, ...)
     g->band_pixels = (size_t)g->strips_per_rank * RM_STRIP_ROWS * e->W;
     g->packed = e->W % 4 == 0 && e->H <= 65535;
     const size_t wire = g->packed ? 3 : 4;
@@ -463,6 +466,14 @@ int rm_group_frame(rm_group *g, void *d_bgra_frame, int fxaa, int32_t mouse_x, i
     if (receives && !s.d_gathered4) HIP_TRY(dev_alloc(&s.d_gathered4, g->band_pixels * 4 * g->world));
     g->next_slot = (g->next_slot + 1) % g->in_flight;
     g->frames++;
+    // Which strips a rank renders rotates from frame to frame: in frame i rank r takes the strips
+    // (r + i) mod world, (r + i) mod world + world, ...  A rank's pace with k frames in flight is bounded
+    // below by the latency of its slowest tiles over k; the slowest tiles of a view (two mirrors that
+    // show each other) lie in a few strips, and whoever holds those in every frame sets the pace of the
+    // whole group.  Rotated, every rank holds them in one frame in `world`, beside two cheaper ones.
+    const int shift = g->rotate ? (int)(g->issued % (unsigned long long)g->world) : 0;
+    const int role = (g->rank + shift) % g->world;
+    g->issued++;
     // Everything of this frame goes to the slot's stream, in order; the frame that used the slot's
     // buffers before it is ahead of it on the same stream.
     hipStream_t own = e->stream;
@@ -478,13 +489,13 @@ int rm_group_frame(rm_group *g, void *d_bgra_frame, int fxaa, int32_t mouse_x, i
             }
             HIP_TRY(hipEventRecord(g->ev0[t], s.stream));
         }
-        if (int r = rm_engine_render_strips_device(e, s.d_strips, (size_t)e->W * 4, g->rank, g->world, g->strips_per_rank)) return r;
+        if (int r = rm_engine_render_strips_device(e, s.d_strips, (size_t)e->W * 4, role, g->world, g->strips_per_rank)) return r;
         if (g->timing) HIP_TRY(hipEventRecord(g->ev1[t], s.stream));
         void *frame = fxaa ? s.d_unfiltered : static_cast<unsigned char *>(d_bgra_frame);
         const auto reorder = [&](const unsigned char *gathered) {
             hipLaunchKernelGGL(reorder_strips_kernel, dim3((e->W + 255) / 256, e->H), dim3(256), 0, s.stream,
                                reinterpret_cast<const unsigned *>(gathered), static_cast<unsigned *>(frame), e->W, e->H, g->world,
-                               g->strips_per_rank);
+                               g->strips_per_rank, shift);
         };
         if (presenter >= 0) {
             // the strips travel as rendered, 4 bytes per pixel: a link carries one frame in `world`, so the
@@ -502,7 +513,7 @@ int rm_group_frame(rm_group *g, void *d_bgra_frame, int fxaa, int32_t mouse_x, i
             if (g->timing) HIP_TRY(hipEventRecord(g->ex0[t], s.stream));
             if (int r = group_all_gather(g, s.comm, s.d_wire, s.d_gathered, g->band_pixels * 3, false, s.stream)) return r;
             if (g->timing) HIP_TRY(hipEventRecord(g->ex1[t], s.stream));
-            if (int r = rm_engine_unpack_bgr_strips_device(e, s.d_gathered, frame, g->world, g->strips_per_rank)) return r;
+            if (int r = unpack_bgr_strips(e, s.d_gathered, frame, g->world, g->strips_per_rank, shift)) return r;
         } else {
             if (g->timing) HIP_TRY(hipEventRecord(g->ex0[t], s.stream));
             if (int r = group_all_gather(g, s.comm, s.d_strips, s.d_gathered, g->band_pixels * 4, false, s.stream)) return r;

@@ -713,15 +713,17 @@ __global__ __launch_bounds__(256) void pack_bgr_kernel(const uint4 *__restrict__
     dst[3 * t + 2] = ((p.z >> 16) & 0xFFu) | (p.w << 8);
 }
 
-// Output row y of the frame comes from packed row ((s % world) * per + s / world) * 8 + y % 8 with
-// s = y / 8: strip s was rendered by rank s % world as its strip number s / world.
+// Output row y of the frame comes from packed row (part * per + s / world) * 8 + y % 8 with s = y / 8
+// and part = (s % world - shift) mod world: strip s is number s / world of the strips s % world,
+// s % world + world, ..., which the rank `shift` places before rank s % world rendered (shift = 0:
+// rank s % world itself; a group rotates the assignment from frame to frame, see rm_group_frame).
 __global__ __launch_bounds__(256) void unpack_bgr_strips_kernel(const unsigned *__restrict__ src, uint4 *__restrict__ dst, int W4,
-                                                                int H, int world, int per) {
+                                                                int H, int world, int per, int shift) {
     const int g = blockIdx.x * 256 + threadIdx.x;  // group of four pixels in the row
     const int y = blockIdx.y;
     if (g >= W4) return;
     const int s = y / RM_STRIP_ROWS;
-    const size_t srow = (size_t)((s % world) * per + s / world) * RM_STRIP_ROWS + (y % RM_STRIP_ROWS);
+    const size_t srow = (size_t)(((s % world - shift + world) % world) * per + s / world) * RM_STRIP_ROWS + (y % RM_STRIP_ROWS);
     const unsigned *w = src + (srow * W4 + g) * 3;
     const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
     uint4 p;
@@ -873,9 +875,12 @@ struct rm_engine {
     unsigned *d_tile_cost = nullptr;    // [frame tiles][4]
     unsigned *d_plan_words = nullptr;   // kPlanRing x (count padded to 64 words + list[kPlanCap])
     unsigned char *d_plan_flags = nullptr;  // kPlanRing x [frame tiles]
-    hipStream_t plan_stream[8] = {};    // the stream each plan of the ring belongs to
-    bool plan_taken[8] = {};
-    unsigned char plan_parity[8] = {};  // which of a plan's two sets of count words its next launch uses
+    static constexpr unsigned kPlans = 32;  // plans kept: one per (stream, set of tiles) that launches frames of this engine
+    hipStream_t plan_stream[kPlans] = {};    // the stream each plan belongs to
+    bool plan_taken[kPlans] = {};
+    unsigned char plan_parity[kPlans] = {};  // which of a plan's two sets of count words its next launch uses
+    unsigned long long plan_used[kPlans] = {};  // when the plan last served a launch (plan_clock)
+    unsigned long long plan_clock = 0;
     // a plan serves the launches that follow it on its stream while they name the same tiles (see launch_render)
     struct PlanKey {
         unsigned grid_x = 0, per = 0, cap = 0;
@@ -884,9 +889,9 @@ struct rm_engine {
             return grid_x == o.grid_x && per == o.per && cap == o.cap && row_begin == o.row_begin && row_end == o.row_end &&
                    tile_row_stride == o.tile_row_stride && blocks_x == o.blocks_x && blocks_y == o.blocks_y;
         }
-    } plan_key[8];
-    unsigned plan_launches[8] = {};       // launches the stream's plans have served since the first
-    unsigned *plan_count_word[8] = {};    // the count word of the plan in force
+    } plan_key[kPlans];
+    unsigned plan_launches[kPlans] = {};       // launches the plan has served since the first
+    unsigned *plan_count_word[kPlans] = {};    // the count word of the plan in force
     int plan_every = -1;                  // a fresh plan every so many launches (RM_PLAN_EVERY)
     int split_threshold = -1;           // ticks; 0 = off; -1 = not read yet (RM_SPLIT_US)
     bool split_on = true;               // rm_engine_set_tile_splitting
@@ -1821,7 +1826,7 @@ int rm_engine_set_camera(rm_engine *e, const float position[3]) {
     return RM_OK;
 }
 
-constexpr unsigned kPlanRing = 8;      // plans, one per stream that launches frames of this engine
+constexpr unsigned kPlanRing = rm_engine::kPlans;  // plans kept per engine
 constexpr unsigned kPlanCap = 1024;    // tiles listed for quarters per launch at most
 constexpr unsigned kPlanCapEarly = 65536;  // ... listed to go first in a long launch
 constexpr unsigned kPlanStride = 64 + kPlanCapEarly;  // words per plan: the count in a line of its own, then the list
@@ -1881,42 +1886,12 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
             HIP_TRY(dev_alloc(&e->d_plan_flags, (size_t)kPlanRing * frame_tiles));
             HIP_TRY(hipDeviceSynchronize());
         }
-        // A plan is written and read in the order of one stream, so each stream that launches frames has a
-        // plan of its own (launches on one stream cannot overlap); a ninth stream's launches go unplanned.
-        static_assert(kPlanRing == 8, "rm_engine::plan_stream holds one stream per plan of the ring");
-        unsigned slot = kPlanRing;
-        for (unsigned i = 0; i < kPlanRing && slot == kPlanRing; i++)
-            if (e->plan_taken[i] && e->plan_stream[i] == e->stream) slot = i;
-        for (unsigned i = 0; i < kPlanRing && slot == kPlanRing; i++)
-            if (!e->plan_taken[i]) {
-                e->plan_taken[i] = true;
-                e->plan_stream[i] = e->stream;
-                slot = i;
-            }
-        if (slot == kPlanRing) {
-            launch_frame_kernel(e, false, grid, a);
-            return RM_OK;
-        }
-        unsigned *const words = e->d_plan_words + (size_t)slot * kPlanStride, *list = words + 64;
-        unsigned char *flag = e->d_plan_flags + (size_t)slot * frame_tiles;
-        a.tile_cost = e->d_tile_cost;
-        a.cost_tiles = (unsigned)frame_tiles;
 #ifdef RM_DIAG_TIME
         a.plan_per = 1u;  // (the timeline build marks a tile's first pixels: whole tiles only)
 #else
         a.plan_per = long_launch ? 1u : 4u;
 #endif
         a.plan_cap = std::min<unsigned>(long_launch ? kPlanCapEarly : kPlanCap, std::max<unsigned>(16u, grid.x / 16u));
-        // A plan stays in force for the launches that follow it on its stream as long as they name the
-        // same tiles: list and flags are left as they are, so every pixel is still rendered exactly once,
-        // and a plan that has aged costs time at worst, like any wrong guess.  A fresh one is made for a
-        // stream's first four launches (the first has no lifetimes to go by, the second no mean to hold
-        // them against: a scene full of slow tiles overflows its list) and every eighth after that - the
-        // plan kernel is 5 us in front of a launch that may take 100.
-        if (e->plan_every < 0) {
-            const char *v = getenv("RM_PLAN_EVERY");  // (1: a fresh plan for every launch)
-            e->plan_every = v ? std::max(1, std::min(atoi(v), 1 << 20)) : 8;
-        }
         rm_engine::PlanKey key;
         key.grid_x = grid.x;
         key.per = a.plan_per;
@@ -1926,6 +1901,46 @@ static int launch_render(rm_engine *e, dim3 grid, const RenderArgs &a0) {
         key.tile_row_stride = a.tile_row_stride;
         key.blocks_x = a.blocks_x;
         key.blocks_y = a.blocks_y;
+        // A plan is written and read in the order of one stream and names the tiles of one launch shape,
+        // so there is a plan per (stream, set of tiles): launches on one stream cannot overlap, and a
+        // stream that alternates between several sets of tiles (a group whose ranks take turns with the
+        // strips, rm_group_frame) finds each set's plan again.  When every plan is taken, a stream gives up
+        // the one of its own it has not used for longest (the launch that read it is ahead of this one on
+        // the same stream); a stream without any goes unplanned.
+        unsigned slot = kPlanRing;
+        for (unsigned i = 0; i < kPlanRing && slot == kPlanRing; i++)
+            if (e->plan_taken[i] && e->plan_stream[i] == e->stream && key == e->plan_key[i]) slot = i;
+        for (unsigned i = 0; i < kPlanRing && slot == kPlanRing; i++)
+            if (!e->plan_taken[i]) {
+                e->plan_taken[i] = true;
+                e->plan_stream[i] = e->stream;
+                e->plan_launches[i] = 0;
+                slot = i;
+            }
+        if (slot == kPlanRing) {
+            for (unsigned i = 0; i < kPlanRing; i++)
+                if (e->plan_stream[i] == e->stream && (slot == kPlanRing || e->plan_used[i] < e->plan_used[slot])) slot = i;
+            if (slot != kPlanRing) e->plan_launches[slot] = 0;
+        }
+        if (slot == kPlanRing) {
+            launch_frame_kernel(e, false, grid, a);
+            return RM_OK;
+        }
+        e->plan_used[slot] = ++e->plan_clock;
+        unsigned *const words = e->d_plan_words + (size_t)slot * kPlanStride, *list = words + 64;
+        unsigned char *flag = e->d_plan_flags + (size_t)slot * frame_tiles;
+        a.tile_cost = e->d_tile_cost;
+        a.cost_tiles = (unsigned)frame_tiles;
+        // A plan stays in force for the launches of its stream and shape that follow it: list and flags
+        // are left as they are, so every pixel is still rendered exactly once, and a plan that has aged
+        // costs time at worst, like any wrong guess.  A fresh one is made for a plan's first four launches
+        // (the first has no lifetimes to go by, the second no mean to hold them against: a scene full of
+        // slow tiles overflows its list) and every eighth after that - the plan kernel is 5 us in front of
+        // a launch that may take 100.
+        if (e->plan_every < 0) {
+            const char *v = getenv("RM_PLAN_EVERY");  // (1: a fresh plan for every launch)
+            e->plan_every = v ? std::max(1, std::min(atoi(v), 1 << 20)) : 8;
+        }
         const unsigned served = e->plan_launches[slot]++;
         // (a long launch always gets a fresh plan: 5 us are nothing to it, and a plan made from the lifetimes
         // of the frame before serves it better than an older one - the 7680x4320 stress frame takes 13.6 ms
@@ -2160,7 +2175,13 @@ int rm_engine_pack_bgr_device(rm_engine *e, const void *d_bgra, void *d_bgr, siz
     return RM_OK;
 }
 
+static int unpack_bgr_strips(rm_engine *e, const void *d_bgr, void *d_bgra_frame, int world, int strips_per_rank, int shift);
 int rm_engine_unpack_bgr_strips_device(rm_engine *e, const void *d_bgr, void *d_bgra_frame, int world, int strips_per_rank) {
+    return unpack_bgr_strips(e, d_bgr, d_bgra_frame, world, strips_per_rank, 0);
+}
+}  // extern "C"
+// (`shift`: part p of the packed rows holds the strips (p + shift) mod world, (p + shift) mod world + world, ...)
+static int unpack_bgr_strips(rm_engine *e, const void *d_bgr, void *d_bgra_frame, int world, int strips_per_rank, int shift) {
     if (!e || !d_bgr || !d_bgra_frame) return fail(RM_ERR_INVALID, "NULL argument");
     if (e->W % 4) return fail(RM_ERR_UNSUPPORTED, "packed rows need a frame width that is a multiple of 4");
     const int strips = (e->H + RM_STRIP_ROWS - 1) / RM_STRIP_ROWS;
@@ -2170,10 +2191,11 @@ int rm_engine_unpack_bgr_strips_device(rm_engine *e, const void *d_bgr, void *d_
     HIP_TRY(hipSetDevice(e->device));
     const int W4 = e->W / 4;
     hipLaunchKernelGGL(unpack_bgr_strips_kernel, dim3((W4 + 255) / 256, e->H), dim3(256), 0, e->stream,
-                       static_cast<const unsigned *>(d_bgr), static_cast<uint4 *>(d_bgra_frame), W4, e->H, world, strips_per_rank);
+                       static_cast<const unsigned *>(d_bgr), static_cast<uint4 *>(d_bgra_frame), W4, e->H, world, strips_per_rank, shift);
     HIP_TRY(hipGetLastError());
     return RM_OK;
 }
+extern "C" {
 
 int rm_engine_trace_primary(rm_engine *e, int32_t *hit, int32_t *steps, float *position) {
     if (!e) return fail(RM_ERR_INVALID, "NULL engine");
