@@ -318,8 +318,9 @@ int rm_engine_set_march_cap(rm_engine *engine, int max_steps);
  * the engine's previous planned launch (RM_SPLIT_US and RM_SPLIT_TIMES_MEAN in the environment set
  * the two; RM_SPLIT_US=0 switches every plan off).  A longer launch of a scene with a spatial index
  * only hands out first, whole, the tiles that took at least twice the mean (RM_EARLY_TIMES_MEAN).
- * Each stream that launches frames of an engine has a plan of its own, up to eight streams; the
- * launches of further streams go unplanned.  On by default.  A caller that keeps several launches of
+ * A plan belongs to a stream and to the set of tiles its launches name (a row range, a selection of
+ * strips); an engine keeps 32 of them, a stream that finds none free gives up the one of its own it
+ * has not used for longest, and a stream that has none goes unplanned.  On by default.  A caller that keeps several launches of
  * one engine in flight, where the machine is busy anyway and the quarters' idle lanes cost
  * throughput, switches it off (rm_group_create does for more than one frame in flight, unless a
  * rank's share is below 20000 tiles, where the plans still pay).  rm_engine_split_tiles waits for

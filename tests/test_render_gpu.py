@@ -305,9 +305,10 @@ def test_slow_tiles_in_quarters_render_the_same_frame(scene, oracle_lightmaps, t
 
 
 def test_planned_launches_on_many_streams(scene, oracle_lightmaps):
-    """Each stream that launches frames of an engine has a plan of its own (eight of them; further
-    streams' launches go unplanned): ten streams render the frame three times each, launches in
-    flight side by side, and every frame equals the one rendered with the plans switched off."""
+    """Each stream that launches frames of an engine has plans of its own (an engine keeps 32; the
+    launches of a stream that finds none free go unplanned): 36 streams render the frame three times
+    each, launches in flight side by side, and every frame equals the one rendered with the plans
+    switched off."""
     import torch
 
     from raymarching_amd import Engine
@@ -324,7 +325,7 @@ def test_planned_launches_on_many_streams(scene, oracle_lightmaps):
     e.render_rows_device(want.data_ptr(), 0, h)
     e.synchronize()
     e.set_tile_splitting(True)
-    streams = [torch.cuda.Stream() for _ in range(10)]
+    streams = [torch.cuda.Stream() for _ in range(36)]
     frames = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in streams]
     torch.cuda.synchronize()
     for turn in range(3):
@@ -337,6 +338,38 @@ def test_planned_launches_on_many_streams(scene, oracle_lightmaps):
             buf.zero_()
         torch.cuda.synchronize()
     e.set_stream(main.cuda_stream)
+    e.close()
+
+
+def test_one_stream_that_cycles_through_more_sets_of_tiles_than_plans_are_kept(scene, oracle_lightmaps):
+    """A plan names the tiles of one launch shape; a stream that cycles through 40 row ranges (more than
+    the 32 plans an engine keeps) gives up the plan it has not used for longest each time, and every
+    range comes out as in the frame rendered with the plans switched off - three times round, so that
+    every plan has been given up and made again."""
+    import torch
+
+    from raymarching_amd import Engine
+
+    lm, _ = oracle_lightmaps
+    w, h = 1280, 720
+    e = Engine(scene, w, h)
+    for i, values in enumerate(lm[-1]):
+        e.set_lightmap(i, values)
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    e.set_tile_splitting(False)
+    want = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    e.render_rows_device(want.data_ptr(), 0, h)
+    e.synchronize()
+    e.set_tile_splitting(True)
+    ranges = [(8 * k, h - 8 * (k % 7)) for k in range(40)]
+    got = torch.zeros_like(want)
+    for turn in range(3):
+        for r0, r1 in ranges:
+            got.zero_()
+            e.render_rows_device(got[r0:].data_ptr(), r0, r1)  # (the pointer names the range's first row)
+            e.synchronize()
+            assert torch.equal(got[r0:r1], want[r0:r1]), (turn, r0, r1)
+            assert not got[:r0].any() and not got[r1:].any(), (turn, r0, r1)
     e.close()
 
 
