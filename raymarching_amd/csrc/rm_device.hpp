@@ -911,7 +911,7 @@ RM_DEV ShadeResult shade_local(const SC &sc, SceneRef sv_of_kernel, int idx, V3 
         asm volatile("" ::: "memory");
     }
 #endif
-    float shade = (RM_ABL & 1) ? 1.0f : relaxed::smooth_shadow_march(sc, pos, to_light, idx, dist, SHADOW_K, lit);
+    float shade = (RM_ABL & 1) ? 1.0f : relaxed::smooth_shadow_march(sc, pos, to_light, idx, dist, SHADOW_K, lit, sv.light_clear);
 #if !defined(RM_NO_STASH)
     if constexpr (kStash) {
         asm volatile("" ::: "memory");
@@ -926,6 +926,15 @@ RM_DEV ShadeResult shade_local(const SC &sc, SceneRef sv_of_kernel, int idx, V3 
 
     diag_lap(DG_SHADOW);
     out.final_colour = ambient + oc * (shade * ds);
+#if defined(RM_DIAG_PROOF)
+    {   // picture of the shadow proof: green where the ray is proven open, blue where the whole wave is, red where marched, grey where no ray is wanted
+        const bool open = relaxed::shadow_stays_open(sc, pos, to_light, LaneIgnore{idx}, dist, SHADOW_K, sv.light_clear);
+        const bool all = wave_all(open || !lit);
+        out.final_colour = !lit ? vc(0.2f, 0.2f, 0.2f) : all ? vc(0.0f, 0.2f, 1.0f) : open ? vc(0.0f, 1.0f, 0.0f) : vc(1.0f, 0.0f, 0.0f);
+        reflectivity = 0.0f;
+        out.reflectivity = 0.0f;
+    }
+#endif
     out.object_colour = oc;
     out.n = n;
     out.reflectivity = reflectivity;

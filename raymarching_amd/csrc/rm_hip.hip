@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -848,6 +849,7 @@ struct rm_engine {
     bool tetra_normals = false;  // objects.rs:142-149
     bool refraction = false;     // engine.rs:196-228
     bool exact_occlusion = false;  // rm_engine_set_exact_occlusion
+    bool shadow_proof = true;      // shadow rays that are proven open are not marched (shadow_stays_open)
     bool fast = false;             // rm_engine_set_precision: the frame kernel of the fast tier
     size_t grid_entries = 0;  // list entries of the spatial index (0 = none)
 
@@ -952,6 +954,22 @@ struct rm_engine {
         sv.tetra_normals = tetra_normals ? 1 : 0;
         sv.refraction = refraction ? 1 : 0;
         sv.exact_occlusion = exact_occlusion ? 1 : 0;
+        sv.light_clear = std::numeric_limits<float>::infinity();
+        for (const HostObject &o : scene.objects) {
+            float at_light, rise;
+            if (o.type == T_XPLANE || o.type == T_YPLANE || o.type == T_ZPLANE) {
+                at_light = o.p[1] * (scene.light[o.type - T_XPLANE] - o.p[0]);  // objects.rs:275,295,315
+                rise = std::fabs(o.p[1]);
+            } else if (o.type == T_PLANE) {
+                at_light = ((scene.light[0] * o.p[0] + scene.light[1] * o.p[1]) + scene.light[2] * o.p[2]) - o.p[3];
+                rise = std::sqrt(o.p[0] * o.p[0] + o.p[1] * o.p[1] + o.p[2] * o.p[2]);
+            } else {
+                continue;
+            }
+            if (!(rise <= 1.001f) || !(at_light == at_light)) sv.light_clear = -std::numeric_limits<float>::infinity();
+            sv.light_clear = std::min(sv.light_clear, at_light);
+        }
+        if (!shadow_proof) sv.light_clear = -std::numeric_limits<float>::infinity();
         sv.stats = d_stats;
         return sv;
     }
@@ -1773,6 +1791,7 @@ rm_engine *rm_engine_create(const rm_scene *scene, int width, int height, int ma
         delete e;
         return nullptr;
     }
+    if (const char *v = getenv("RM_SHADOW_PROOF")) e->shadow_proof = atoi(v) != 0;  // (0: every wanted shadow ray is marched; for measurements and tests)
     if (const char *v = getenv("RM_TWO_PASS")) e->two_pass = std::max(0, std::min(1 << 20, atoi(v) == 1 ? 8192 : atoi(v)));  // experiment switch
     const float zero[3] = {0.0f, 0.0f, 0.0f};
     rm_engine_input(e, 0, 0, zero, 0);

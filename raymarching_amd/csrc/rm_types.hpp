@@ -147,6 +147,12 @@ struct SceneView {
     int tetra_normals;  // 1 = the four-point normal of objects.rs:142-149 (commented out there)
     int refraction;     // 1 = the refraction block of engine.rs:196-228 (commented out there)
     int exact_occlusion;  // 1 = the lightmap precompute marches every patch pair, as radiosity.rs:130-141 does (see rm_engine_set_exact_occlusion)
+    // The smallest distance from the light to any plane of the scene, as the march loops compute plane
+    // distances (+inf without planes): a shadow ray of length L ends at the light, so no plane is nearer
+    // than L / k to its far end while L / k stays below this (shadow_stays_open).  Minus infinity where a
+    // plane's distance function rises faster than 1 per unit of length (a direction or normal longer
+    // than 1.001), which that proof's error bounds do not allow for.
+    float light_clear;
     unsigned long long *stats;
 };
 
