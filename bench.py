@@ -785,7 +785,9 @@ def main():
                 # quarters): the events then also span the plan's 5 us kernel
                 "kernel_ms_spans_the_launch_plan": bool(tiles < 65536 and (in_flight == 1 or gathering) and not args.ssaa and not args.refraction),
                 "algorithmic_flops_per_launch": int(flops * band_share),
-                "note": "FP32 vector ALU bound (no MFMA, HBM traffic is 4 B per ray); strict IEEE parity forbids FMA contraction",
+                "note": "FP32 vector ALU bound (no MFMA, HBM traffic is 4 B per ray); strict IEEE parity forbids FMA contraction; the flops are "
+                "those of the reference's algorithm as the oracle counts them: work the kernel proves away (shadow rays whose way to the light "
+                "is provably open, spheres out of a step's reach, the first step of a primary march) counts as done",
             }
             if per_frame_kernel:
                 srt = sorted(per_frame_kernel)
