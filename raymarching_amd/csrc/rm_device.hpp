@@ -368,6 +368,7 @@ struct SceneSmallAcc {
     RM_DEV void boxes(F &&) const {}  // scenes with boxes or smooth unions use the large layout
     static constexpr bool kSmooth = false;
     static constexpr bool kGrid = false;
+    static constexpr int kSphereSlots = G::kSpheres;  // spheres() hands out indices below this
     RM_DEV float sphere_extent() const { return g.sph_extent; }
     static constexpr bool kUnitAxis = G::kExact;  // the exact-fill tier also promises |dir| = 1 on every axis plane
     RM_DEV float smooth_k() const { return 0.0f; }
@@ -436,6 +437,7 @@ struct SceneLargeAcc {
     }
     static constexpr bool kSmooth = true;
     static constexpr bool kGrid = true;
+    static constexpr int kSphereSlots = 0;
     RM_DEV const GridView &grid() const { return g.grid; }
     RM_DEV float sphere_extent() const { return g.sph_extent; }
     static constexpr bool kUnitAxis = false;
