@@ -1007,7 +1007,7 @@ RM_DEV V3 cast_sight_ray(const SC &sc, SceneRef sv, V3 pos, V3 dir, float first 
             }
         } else
 #endif
-            idx = march(sc, pos, dir, -1, sv.march_cap, steps, capped, first, first_sph);
+            idx = march<true>(sc, pos, dir, -1, sv.march_cap, steps, capped, first, first_sph);
         first = __builtin_nanf("");  // known for the ray from the camera only
         if (capped) atomicAdd(&sv.stats[1], 1ULL);
         if (idx < 0) {
